@@ -1,0 +1,161 @@
+/*
+ * v3d_hip.h -- C ABI of libv3d_hip.so, the gfx950 (MI355X) replacement for the CUDA half of the
+ * reference's `vision3d.ext` extension (/root/reference/vision3d/csrc/pybind.cpp:71-158).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes, no torch types; the caller owns every buffer and pre-allocates every
+ *     output exactly as the reference's Python wrappers do (vision3d/ops/<op>.py);
+ *   - `device` is the HIP device ordinal the buffers live on, `stream` a hipStream_t passed as void*
+ *     (NULL = the device's default stream).  Work is enqueued asynchronously; nothing synchronises, nothing
+ *     is retained after the enqueued work ends (same as the reference launchers: CUDAGuard +
+ *     getCurrentCUDAStream + launch + cudaGetLastError, e.g. ball_query_cuda.cu:16-38);
+ *   - return value: 0 = enqueued; > 0 = a hipError_t from launch / runtime; < 0 = a V3D_ERR_* validation
+ *     code.  Never throws.  v3d_last_error_string() describes the calling thread's last failure;
+ *   - index tensors are int64 ("long", torch_helper.h:21); values are narrowed to 32 bit inside the kernels
+ *     exactly like the reference (`int source_index = indices[...]`, group_gather_cuda.cuh:30), while all
+ *     ADDRESS arithmetic is 64 bit (the reference overflows `int` past 2^31 elements; we do not);
+ *   - squared distances are evaluated in "reference order" ((dx*dx + dy*dy) + dz*dz, one rounding per
+ *     operation, no FMA contraction), see DESIGN.md.
+ */
+#ifndef V3D_HIP_H_
+#define V3D_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V3D_OK 0
+#define V3D_ERR_INVALID_ARGUMENT (-1) /* null pointer, negative size, unsupported element width ... */
+#define V3D_ERR_K_TOO_LARGE (-2)      /* knn_points: k > 100 (reference: best_dist[100], knn_points_cuda.cuh:68) */
+#define V3D_ERR_WORKSPACE (-3)        /* caller workspace smaller than v3d_scatter_workspace_bytes() */
+#define V3D_ERR_SIZE_LIMIT (-4)       /* a dimension exceeds what the 32-bit index VALUES can express */
+
+#define V3D_KNN_MAX_K 100
+
+/* Library identification / diagnostics (no reference counterpart). */
+int v3d_version(void);                       /* 10000*major + 100*minor + patch */
+const char* v3d_last_error_string(void);     /* thread-local, never NULL */
+const char* v3d_error_name(int code);        /* "V3D_OK", "V3D_ERR_K_TOO_LARGE", or the hipGetErrorName text */
+int v3d_device_count(int* count);            /* hipGetDeviceCount wrapper used by the host shim's load check */
+
+/* ---- furthest point sampling ------------------------------------------------------------------------
+ * replaces vision3d::furthest_point_sample (csrc/cuda/furthest_point_sample/furthest_point_sample.cpp:5-8,
+ * launcher furthest_point_sample_cuda.cu:5-73, kernel furthest_point_sample_cuda.cuh:29-88).
+ * points (B,N,3) f32; distances (B,N) f32 in/out scratch, arrives filled with 1e10
+ * (ops/furthest_point_sample.py:34) and leaves holding the final min-distances as in the reference;
+ * indices (B,M) i64.  Ties between equally far points are resolved as the reference's launch geometry
+ * does (block = v3d_fps_ref_block(N)), independent of our own geometry. */
+int v3d_fps_ref_block(int num_points);       /* opt_n_threads, furthest_point_sample_cuda.cuh:9-12 */
+int v3d_fps_f32(const float* points, float* distances, int64_t* indices, int B, int N, int M, int device,
+                void* stream);
+
+/* ---- ball query -------------------------------------------------------------------------------------
+ * replaces vision3d::ball_query (csrc/cuda/ball_query/ball_query.h:7-12; kernel ball_query_cuda.cuh:11-55).
+ * q (B,M,3), s (B,N,3), indices (B,M,k) i64 arriving zero-filled (ops/ball_query.py:38): slots of a query
+ * with no neighbour are left untouched, as in the reference.  max_radius is a C float in both variants
+ * (ball_query.h:11) and squared in the element type (ball_query_cuda.cuh:28). */
+int v3d_ball_query_f32(const float* q, const float* s, int64_t* indices, int B, int M, int N, float max_radius,
+                       int k, int device, void* stream);
+int v3d_ball_query_f64(const double* q, const double* s, int64_t* indices, int B, int M, int N,
+                       float max_radius, int k, int device, void* stream);
+
+/* ---- knn_points (3-D, heap based) -------------------------------------------------------------------
+ * replaces vision3d::knn_points (csrc/cuda/knn_points/knn_points.h; kernel knn_points_cuda.cuh:41-93),
+ * also reachable as `knn` through the host shim (ops/knn_points.py:36 calls ext.knn).
+ * distances (B,M,k) = sqrt of squared distance ascending, indices (B,M,k); N<k leaves trailing (1e5, 0).
+ * Equal distances come out in the order the reference's heap produces.  k > 100 -> V3D_ERR_K_TOO_LARGE. */
+int v3d_knn_points_f32(const float* q, const float* s, float* distances, int64_t* indices, int B, int M, int N,
+                       int k, int device, void* stream);
+int v3d_knn_points_f64(const double* q, const double* s, double* distances, int64_t* indices, int B, int M,
+                       int N, int k, int device, void* stream);
+
+/* ---- three_nn ---------------------------------------------------------------------------------------
+ * replaces vision3d::three_nn (csrc/cuda/three_nn/three_nn.h; kernel three_nn_cuda.cuh:11-75).
+ * q (B,Q,3), s (B,S,3) -> distances (B,Q,3) (sqrt), indices (B,Q,3); S<3 leaves (1e20, -1) in the
+ * unfilled slots like the reference's 1e40 / -1 initialisers (:37-42,:67-73). */
+int v3d_three_nn_f32(const float* q, const float* s, float* distances, int64_t* indices, int B, int Q, int S,
+                     int device, void* stream);
+int v3d_three_nn_f64(const double* q, const double* s, double* distances, int64_t* indices, int B, int Q, int S,
+                     int device, void* stream);
+
+/* Count of supports strictly inside `radius` of each query (no kernel in the reference: it evaluates
+ * relu(radius - |q-s|).sign().sum() with pykeops, ops/radius_search.py:74-81).  counts (B,M) i64. */
+int v3d_radius_count_f32(const float* q, const float* s, int64_t* counts, int B, int M, int N, float radius,
+                         int device, void* stream);
+
+/* ---- three_interpolate ------------------------------------------------------------------------------
+ * replaces vision3d::three_interpolate_forward / _backward (csrc/cuda/three_interpolate/three_interpolate.h;
+ * kernels three_interpolate_cuda.cuh:11-44 and :48-83).
+ * sources (B,C,S), indices (B,Q,3) i64, weights (B,Q,3), targets (B,C,Q).
+ * Backward: source_grads (B,C,S) is fully overwritten (the reference accumulates into a zero-filled buffer
+ * with atomics; we write the sum once, atomic-free and bit-reproducible, in ascending (q,j) order).
+ * It needs scratch: pass `workspace` of at least v3d_scatter_workspace_bytes(B, S, Q*3) bytes on the same
+ * device (256-B aligned), or NULL to let the library hipMallocAsync/hipFreeAsync it on `stream`. */
+int v3d_three_interp_fwd_f32(const float* sources, const int64_t* indices, const float* weights, float* targets,
+                             int B, int C, int S, int Q, int device, void* stream);
+int v3d_three_interp_fwd_f64(const double* sources, const int64_t* indices, const double* weights,
+                             double* targets, int B, int C, int S, int Q, int device, void* stream);
+size_t v3d_scatter_workspace_bytes(int B, int num_sources, int64_t positions_per_batch);
+int v3d_three_interp_bwd_f32(const float* target_grads, const int64_t* indices, const float* weights,
+                             float* source_grads, int B, int C, int S, int Q, void* workspace,
+                             size_t workspace_bytes, int device, void* stream);
+int v3d_three_interp_bwd_f64(const double* target_grads, const int64_t* indices, const double* weights,
+                             double* source_grads, int B, int C, int S, int Q, void* workspace,
+                             size_t workspace_bytes, int device, void* stream);
+
+/* ---- gather / group_gather --------------------------------------------------------------------------
+ * replace vision3d::gather_forward/_backward (csrc/cuda/gather/gather.h; gather_cuda.cuh:11-33,37-59) and
+ * vision3d::group_gather_forward/_backward (csrc/cuda/group_gather/group_gather.h;
+ * group_gather_cuda.cuh:11-33,37-59).
+ * Forward: sources (B,C,N) of ANY element type of `elem_bytes` in {1,2,4,8} (the reference dispatches
+ * AT_DISPATCH_ALL_TYPES_AND(Bool), gather_cuda.cu:22 / group_gather_cuda.cu:23 -- a gather is a byte copy);
+ * indices (B,M) resp. (B,M,K) i64; targets (B,C,M) resp. (B,C,M,K).
+ * Backward (f32/f64, gather_cuda.cu:53): source_grads (B,C,N) fully overwritten, atomic-free, summed in
+ * ascending target order (== the CPU oracle's sequential loop, bit for bit).  Workspace as above with
+ * positions_per_batch = M resp. M*K. */
+int v3d_gather_fwd(const void* sources, const int64_t* indices, void* targets, int B, int C, int N, int M,
+                   int elem_bytes, int device, void* stream);
+int v3d_group_gather_fwd(const void* sources, const int64_t* indices, void* targets, int B, int C, int N, int M,
+                         int K, int elem_bytes, int device, void* stream);
+int v3d_gather_bwd_f32(const float* target_grads, const int64_t* indices, float* source_grads, int B, int C,
+                       int N, int M, void* workspace, size_t workspace_bytes, int device, void* stream);
+int v3d_gather_bwd_f64(const double* target_grads, const int64_t* indices, double* source_grads, int B, int C,
+                       int N, int M, void* workspace, size_t workspace_bytes, int device, void* stream);
+int v3d_group_gather_bwd_f32(const float* target_grads, const int64_t* indices, float* source_grads, int B,
+                             int C, int N, int M, int K, void* workspace, size_t workspace_bytes, int device,
+                             void* stream);
+int v3d_group_gather_bwd_f64(const double* target_grads, const int64_t* indices, double* source_grads, int B,
+                             int C, int N, int M, int K, void* workspace, size_t workspace_bytes, int device,
+                             void* stream);
+
+/* ---- pairwise_distance / feature-space KNN ----------------------------------------------------------
+ * v3d_pairwise_distance_f32 computes what ops/pairwise_distance.py:39-56 computes with torch.matmul and
+ * 3-4 elementwise passes, in one kernel (fp32-input MFMA for the -2*x.y^T term, norms/clamp/sqrt in the
+ * epilogue).  x (batch,N,C), y (batch,M,C) row-major ("transposed=False" layout), out (batch,N,M).
+ * flags: bit0 normalized (d = 2 - 2xy, :46-47), bit1 non-squared (d = sqrt(d + eps), :55-56), bit2 strict (the
+ * exact difference form of :28-37 on the VALU: sum_c (x_c-y_c)^2, or its sqrt with bit1; no clamp, no eps).
+ * v3d_knn_feat_f32 is the fused form behind ops/knn.py:10-27 (pykeops Kmin_argKmin of the Euclidean norm):
+ * k smallest by (distance, index), distances (batch,N,k) NOT squared, indices (batch,N,k) i64, offset by
+ * `index_offset` (reference-set sharding).  k <= 64.  `workspace` as above, size from
+ * v3d_knn_feat_workspace_bytes(); NULL = stream-ordered allocation. */
+#define V3D_PD_NORMALIZED 1
+#define V3D_PD_SQRT 2
+#define V3D_PD_STRICT 4
+int v3d_pairwise_distance_f32(const float* x, const float* y, float* out, int batch, int N, int M, int C,
+                              int flags, float eps, int device, void* stream);
+size_t v3d_knn_feat_workspace_bytes(int batch, int N, int M, int C, int k);
+int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* indices, int batch, int N,
+                     int M, int C, int k, int64_t index_offset, void* workspace, size_t workspace_bytes,
+                     int device, void* stream);
+/* Merge G sorted partial top-k lists per row (the all-gathered shards of a reference-set partition) into the
+ * global top-k: parts_* (G, rows, k) -> out_* (rows, k), ordered by (distance, index). */
+int v3d_topk_merge_f32(const float* parts_dist, const int64_t* parts_idx, float* out_dist, int64_t* out_idx,
+                       int G, int64_t rows, int k, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V3D_HIP_H_ */

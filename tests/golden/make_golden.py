@@ -1,0 +1,127 @@
+"""Generates the committed golden fixtures under tests/golden/ (run once, in the build container).
+
+Two kinds of fixture, kept apart by file name:
+
+* ``ref_*.npz``  -- inputs + outputs of the REFERENCE's own importable Python, loaded by file path from
+  /root/reference (read-only; the reference cannot travel to the GPU box, so only these vectors do):
+    - vision3d/ops/pairwise_distance.py         (pure torch, CPU)          -> ref_pairwise_distance.npz
+    - vision3d/array_ops/knn.py                 (scipy cKDTree.query)       -> ref_array_knn.npz
+    - vision3d/array_ops/ball_query.py          (cKDTree.query_ball_point)  -> ref_array_ball_query.npz
+  The CUDA kernels themselves cannot be built or run here (no nvcc, no GPU) and ship no test vectors.
+* ``oracle_*.npz`` -- regression vectors of OUR CPU oracle on tie-stress inputs (lattices, duplicates, N<k,
+  empty balls).  They pin the oracle against drift and give the GPU tests a file-based target; they are NOT
+  evidence about the reference (tie order there is "parity unpinned").
+
+Usage:  python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/vision3d"
+sys.path.insert(0, REPO)
+
+import oracle  # noqa: E402
+
+
+def load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        spec.loader.exec_module(mod)
+    return mod
+
+
+def unit_sphere_cloud(rng, b, n):
+    """ModelNet40-shaped synthetic cloud: N(0,1)^3, centred, scaled into the unit sphere."""
+    p = rng.standard_normal((b, n, 3)).astype(np.float32)
+    p -= p.mean(axis=1, keepdims=True)
+    p /= np.linalg.norm(p, axis=2).max(axis=1)[:, None, None]
+    return p.astype(np.float32)
+
+
+def make_reference_fixtures():
+    rng = np.random.default_rng(20261110)
+    # ---- pairwise_distance: every flag combination of the reference function --------------------------
+    pd = load_by_path("ref_pairwise_distance", os.path.join(REF, "ops", "pairwise_distance.py"))
+    x = rng.standard_normal((2, 37, 20)).astype(np.float32)
+    y = rng.standard_normal((2, 45, 20)).astype(np.float32)
+    xn = x / np.linalg.norm(x, axis=-1, keepdims=True)
+    yn = y / np.linalg.norm(y, axis=-1, keepdims=True)
+    out = {"x": x, "y": y, "xn": xn.astype(np.float32), "yn": yn.astype(np.float32)}
+    for normalized in (False, True):
+        for squared in (False, True):
+            for strict in (False, True):
+                for transposed in (False, True):
+                    a, b = (xn, yn) if normalized else (x, y)
+                    ta, tb = torch.from_numpy(a.astype(np.float32)), torch.from_numpy(b.astype(np.float32))
+                    if transposed:
+                        ta, tb = ta.transpose(-1, -2).contiguous(), tb.transpose(-1, -2).contiguous()
+                    d = pd.pairwise_distance(ta, tb, normalized=normalized, transposed=transposed, squared=squared,
+                                             strict=strict)
+                    key = f"d_n{int(normalized)}_s{int(squared)}_t{int(strict)}_T{int(transposed)}"
+                    out[key] = d.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "ref_pairwise_distance.npz"), **out)
+
+    # ---- array_ops.knn / array_ops.ball_query (scipy) -------------------------------------------------
+    aknn = load_by_path("ref_array_knn", os.path.join(REF, "array_ops", "knn.py"))
+    aball = load_by_path("ref_array_ball_query", os.path.join(REF, "array_ops", "ball_query.py"))
+    s = unit_sphere_cloud(rng, 1, 600)[0]
+    q = s[rng.permutation(600)[:150]] + rng.normal(0, 0.01, (150, 3)).astype(np.float32)
+    q = q.astype(np.float32)
+    kd, ki = aknn.knn(q, s, k=8, return_distance=True)
+    np.savez_compressed(os.path.join(HERE, "ref_array_knn.npz"), q=q, s=s, k=np.int64(8),
+                        dist=kd.astype(np.float64), idx=ki.astype(np.int64))
+    radius = 0.2
+    lists = aball.ball_query(q, s, radius)
+    flat = np.concatenate([np.sort(np.asarray(l, dtype=np.int64)) for l in lists]) if len(lists) else np.zeros(0)
+    lens = np.asarray([len(l) for l in lists], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "ref_array_ball_query.npz"), q=q, s=s, radius=np.float32(radius),
+                        flat=flat.astype(np.int64), lens=lens)
+
+
+def make_oracle_fixtures():
+    rng = np.random.default_rng(7)
+    # lattice: 6x6x6 integer grid scaled by 0.25 -> massive distance ties, exactly representable
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6), indexing="ij"), -1).reshape(-1, 3)
+    lattice = (g.astype(np.float32) * 0.25)[None]  # (1, 216, 3)
+    perm = rng.permutation(216)
+    lattice_shuffled = lattice[:, perm]
+    dup = np.repeat(unit_sphere_cloud(rng, 1, 40), 3, axis=1)  # every point three times
+    rand100 = rng.random((2, 100, 3), dtype=np.float32)  # N=100 -> reference block 64 (not a divisor)
+    clouds = {"lattice": lattice, "lattice_shuffled": lattice_shuffled, "dup": dup, "rand100": rand100}
+    out = {}
+    for name, pts in clouds.items():
+        n = pts.shape[1]
+        m = min(n, 48)
+        out[f"{name}_pts"] = pts
+        out[f"{name}_fps"] = oracle.furthest_point_sample(pts, m)
+        qs = pts[:, : min(n, 32)]
+        out[f"{name}_ball"] = oracle.ball_query(qs, pts, 8, 0.3)
+        kd, ki = oracle.knn_points(qs, pts, 12)
+        out[f"{name}_knn_d"], out[f"{name}_knn_i"] = kd, ki
+        td, ti = oracle.three_nn(qs, pts)
+        out[f"{name}_tnn_d"], out[f"{name}_tnn_i"] = td, ti
+    # N < k and empty balls
+    tiny = rng.random((1, 5, 3), dtype=np.float32)
+    out["tiny_pts"] = tiny
+    kd, ki = oracle.knn_points(tiny, tiny, 9)
+    out["tiny_knn_d"], out["tiny_knn_i"] = kd, ki
+    out["tiny_ball_empty"] = oracle.ball_query(tiny + 10.0, tiny, 4, 0.1)
+    np.savez_compressed(os.path.join(HERE, "oracle_ties.npz"), **out)
+
+
+if __name__ == "__main__":
+    oracle.build()
+    make_reference_fixtures()
+    make_oracle_fixtures()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,130 @@
+"""Host-side logic that needs no GPU: argument validation (reference messages), pack/batch conversion,
+kNN post-processing, and the `vision3d` aliasing."""
+import importlib
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import vision3d_amd
+from vision3d_amd import ext
+from vision3d_amd.ops import conversion
+
+knn_mod = importlib.import_module("vision3d_amd.ops.knn")
+
+
+def test_ext_exports_reference_names():
+    # csrc/pybind.cpp:72-158 (+ the `knn` alias used by ops/knn_points.py:36)
+    for name in ("ball_query", "furthest_point_sample", "gather_forward", "gather_backward", "group_gather_forward",
+                 "group_gather_backward", "three_nn", "three_interpolate_forward", "three_interpolate_backward",
+                 "knn_points", "knn"):
+        assert callable(getattr(ext, name))
+    assert ext.knn is ext.knn_points
+
+
+def test_validation_messages_match_torch_helper():
+    q = torch.zeros(1, 4, 3)
+    idx = torch.zeros(1, 4, 2, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="q_points must be a CUDA tensor"):
+        ext.ball_query(q, q, idx, 0.1, 2)
+    with pytest.raises(RuntimeError, match="points must be a CUDA tensor"):
+        ext.furthest_point_sample(q, torch.zeros(1, 4), torch.zeros(1, 2, dtype=torch.long), 2)
+    with pytest.raises(RuntimeError, match="sources must be a CUDA tensor"):
+        ext.group_gather_forward(torch.zeros(1, 2, 4), idx, torch.zeros(1, 2, 4, 2))
+    with pytest.raises(RuntimeError, match="CUDA tensors"):
+        from vision3d_amd.ops import pairwise_distance
+        pairwise_distance(torch.zeros(3, 2), torch.zeros(4, 2))
+
+
+def test_keyword_names_match_pybind():
+    import inspect
+
+    expect = {
+        "ball_query": ["q_points", "s_points", "indices", "max_radius", "num_samples"],
+        "furthest_point_sample": ["points", "distances", "indices", "num_samples"],
+        "gather_forward": ["sources", "indices", "targets"],
+        "gather_backward": ["target_grads", "indices", "source_grads", "num_sources"],
+        "group_gather_forward": ["sources", "indices", "targets"],
+        "group_gather_backward": ["target_grads", "indices", "source_grads", "num_sources"],
+        "three_nn": ["q_points", "s_points", "tnn_distances", "tnn_indices"],
+        "three_interpolate_forward": ["sources", "indices", "weights", "targets"],
+        "three_interpolate_backward": ["target_grads", "indices", "weights", "source_grads", "num_sources"],
+        "knn_points": ["q_points", "s_points", "knn_distances", "knn_indices", "num_neighbors"],
+    }
+    for name, args in expect.items():
+        assert list(inspect.signature(getattr(ext, name)).parameters) == args, name
+
+
+def test_pack_batch_round_trip():
+    lengths = torch.tensor([3, 0, 5, 1])
+    pack = torch.arange(9 * 2, dtype=torch.float32).view(9, 2)
+    batch, masks = conversion.pack_to_batch(pack, lengths, fill_value=1e10)
+    assert batch.shape == (4, 5, 2) and masks.sum().item() == 9
+    assert torch.equal(masks.sum(1), lengths)
+    assert torch.all(batch[~masks] == 1e10)
+    back, l2 = conversion.batch_to_pack(batch, masks)
+    assert torch.equal(back, pack) and torch.equal(l2, lengths)
+    back2, _ = conversion.batch_to_pack_with_lengths(batch, lengths)
+    assert torch.equal(back2, pack)
+    b3, m3 = conversion.pack_to_batch(pack, lengths, max_length=7)
+    assert b3.shape == (4, 7, 2) and torch.equal(m3.sum(1), lengths)
+
+
+def test_knn_post_processing(monkeypatch):
+    """dilation / remove_nearest / distance_limit / squeeze follow ops/knn.py:72-107; the search itself is faked."""
+    def fake_search(q, s, k):
+        d = torch.cdist(q, s)
+        dist, idx = torch.sort(d, dim=-1, stable=True)
+        return dist[..., :k].contiguous(), idx[..., :k].contiguous()
+
+    monkeypatch.setattr(knn_mod, "keops_knn", fake_search)
+    g = torch.Generator().manual_seed(0)
+    q = torch.rand(2, 6, 3, generator=g)
+    s = torch.rand(2, 20, 3, generator=g)
+    full_d, full_i = fake_search(q, s, 20)
+    idx = knn_mod.knn(q, s, 4)
+    assert torch.equal(idx, full_i[..., :4])
+    d, idx = knn_mod.knn(q, s, 3, dilation=2, return_distance=True)
+    assert torch.equal(idx, full_i[..., 0:5:2]) and torch.equal(d, full_d[..., 0:5:2])
+    idx = knn_mod.knn(q, s, 3, remove_nearest=True)
+    assert torch.equal(idx, full_i[..., 1:4])
+    lim = float(full_d[..., 2].median())
+    d, idx = knn_mod.knn(q, s, 4, distance_limit=lim, return_distance=True)
+    far = full_d[..., :4] >= lim
+    assert torch.equal(idx[far], full_i[..., :1].expand(-1, -1, 4)[far])
+    d, idx = knn_mod.knn(q, s, 4, distance_limit=lim, return_distance=True, padding_mode="empty")
+    assert torch.all(idx[far] == 20) and torch.all(d[far] == 1e10)
+    idx = knn_mod.knn(q, s, 1, squeeze=True)
+    assert idx.shape == (2, 6)
+    idx = knn_mod.knn(q.transpose(1, 2), s.transpose(1, 2), 2, transposed=True)
+    assert torch.equal(idx, full_i[..., :2])
+    idx = knn_mod.knn(q, s, 30)  # k larger than the support set is clipped (knn.py:75)
+    assert idx.shape[-1] == 20
+
+
+def test_install_aliases_modules():
+    saved = {k: sys.modules.get(k) for k in ("vision3d", "vision3d.ext", "vision3d.ops")}
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        vision3d_amd.install()
+        m = importlib.import_module("vision3d.ext")  # what the reference's load_ext does (utils/misc.py:23-27)
+        for fn in ("ball_query", "knn_points", "knn", "three_nn", "group_gather_forward"):
+            assert hasattr(m, fn)
+        from vision3d.ops import ball_query, furthest_point_sample, group_gather  # noqa: F401
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from vision3d_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
+        _lib.lib()

@@ -1,0 +1,503 @@
+// gather.hip -- gather / group_gather forward (any element width) and the atomic-free backward shared with
+// three_interpolate.  Replaces gather_cuda.cuh / group_gather_cuda.cuh / the backward half of
+// three_interpolate_cuda.cuh of the reference (semantics only; the design is gfx950-first).
+//
+// Forward  out[b,c,t] = src[b,c,idx[b,t]]  (t runs over the M resp. M*K flat target positions):
+//   HBM-write bound.  One workgroup owns a tile of target positions of one cloud and walks a TILE OF
+//   CHANNELS with the indices held in registers (the reference re-reads the int64 index tensor once per
+//   channel).  Stores are 16 B per lane.  Two source paths:
+//     * lds   : the (b,c) source row is staged in LDS (double buffered, one barrier per channel) and the
+//               random 4-byte reads hit LDS banks instead of the vector L1;
+//     * direct: rows too large for LDS are gathered straight from global memory (L2-resident).
+// Backward grad_src[b,c,n] = sum_{t: idx[b,t]==n} grad_out[b,c,t]:
+//   the index tensor is inverted once per call into a CSR (count -> scan -> fill -> rank-sort, 32-bit
+//   integer atomics only on the tiny count/cursor arrays), then every (b,c,n) is summed by ONE thread in
+//   ascending t.  No float atomics, bit-reproducible, equal to the sequential CPU loop.
+#include "common.h"
+
+namespace v3d {
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+template <typename E, int VEC>
+struct alignas(sizeof(E) * VEC) Pack {
+  E v[VEC];
+};
+
+constexpr int kGatherThreads = 256;
+
+// Index fetch with the reference's long -> int narrowing (group_gather_cuda.cuh:30); out-of-range values
+// (undefined behaviour in the reference) are mapped to -1 and produce zeros instead of a fault.
+__device__ __forceinline__ int fetch_index(const int64_t* __restrict__ idx, int64_t pos, int64_t limit, int N) {
+  if (pos >= limit) return -1;
+  int v = (int)idx[pos];
+  return (v >= 0 && v < N) ? v : -1;
+}
+
+template <typename E, int VEC, int R, bool VEC_STORE>
+__global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
+    const E* __restrict__ src, const int64_t* __restrict__ idx, E* __restrict__ out, int C, int N, int64_t L,
+    int CT, int row_vec_ok) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CT;
+  const int c1 = min(c0 + CT, C);
+  const int64_t tile0 = (int64_t)blockIdx.x * (kGatherThreads * VEC * R);
+  const size_t row_bytes = ((size_t)N * sizeof(E) + 15) & ~(size_t)15;
+  E* buf[2] = {reinterpret_cast<E*>(smem_raw), reinterpret_cast<E*>(smem_raw + row_bytes)};
+
+  int my[R][VEC];
+  const int64_t* bidx = idx + (int64_t)b * L;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) my[r][e] = fetch_index(bidx, p0 + e, L, N);
+  }
+
+  constexpr int kRowVec = 16 / sizeof(E);  // elements per 16-byte staging vector
+  constexpr int kMaxStage = 8;             // host guarantees N*sizeof(E) <= 8*256*16 = 32 KiB
+  const int nvec = (int)(((size_t)N * sizeof(E)) / 16);
+
+  auto stage_row_sync = [&](int c, E* dst) {  // first row: plain load + store
+    const E* row = src + ((int64_t)b * C + c) * N;
+    if (row_vec_ok) {
+      const uint4* row4 = reinterpret_cast<const uint4*>(row);
+      uint4* dst4 = reinterpret_cast<uint4*>(dst);
+      for (int i = tid; i < nvec; i += kGatherThreads) dst4[i] = row4[i];
+      for (int i = nvec * kRowVec + tid; i < N; i += kGatherThreads) dst[i] = row[i];
+    } else {
+      for (int i = tid; i < N; i += kGatherThreads) dst[i] = row[i];
+    }
+  };
+
+  stage_row_sync(c0, buf[0]);
+  for (int c = c0; c < c1; ++c) {
+    __syncthreads();
+    const E* cur = buf[(c - c0) & 1];
+    E* nxt = buf[(c - c0 + 1) & 1];
+    const bool have_next = (c + 1 < c1);
+    // issue the next row's global loads before the gathers so their latency hides under the stores
+    uint4 stg[kMaxStage];
+    const E* nrow = src + ((int64_t)b * C + (c + 1)) * N;
+    if (have_next && row_vec_ok) {
+      const uint4* row4 = reinterpret_cast<const uint4*>(nrow);
+#pragma unroll
+      for (int i = 0; i < kMaxStage; ++i) {
+        int v = i * kGatherThreads + tid;
+        if (v < nvec) stg[i] = row4[v];
+      }
+    }
+    E* orow = out + ((int64_t)b * C + c) * L;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
+      if (p0 >= L) continue;
+      Pack<E, VEC> pk;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pk.v[e] = my[r][e] >= 0 ? cur[my[r][e]] : E(0);
+      if (VEC_STORE) {
+        *reinterpret_cast<Pack<E, VEC>*>(orow + p0) = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (p0 + e < L) orow[p0 + e] = pk.v[e];
+      }
+    }
+    if (have_next) {
+      if (row_vec_ok) {
+        uint4* dst4 = reinterpret_cast<uint4*>(nxt);
+#pragma unroll
+        for (int i = 0; i < kMaxStage; ++i) {
+          int v = i * kGatherThreads + tid;
+          if (v < nvec) dst4[v] = stg[i];
+        }
+        for (int i = nvec * kRowVec + tid; i < N; i += kGatherThreads) nxt[i] = nrow[i];
+      } else {
+        for (int i = tid; i < N; i += kGatherThreads) nxt[i] = nrow[i];
+      }
+    }
+  }
+}
+
+template <typename E, int VEC, int R, bool VEC_STORE>
+__global__ __launch_bounds__(kGatherThreads) void gather_fwd_direct_kernel(
+    const E* __restrict__ src, const int64_t* __restrict__ idx, E* __restrict__ out, int C, int N, int64_t L,
+    int CT) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CT;
+  const int c1 = min(c0 + CT, C);
+  const int64_t tile0 = (int64_t)blockIdx.x * (kGatherThreads * VEC * R);
+  int my[R][VEC];
+  const int64_t* bidx = idx + (int64_t)b * L;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) my[r][e] = fetch_index(bidx, p0 + e, L, N);
+  }
+#pragma unroll 2
+  for (int c = c0; c < c1; ++c) {
+    const E* row = src + ((int64_t)b * C + c) * N;
+    E* orow = out + ((int64_t)b * C + c) * L;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
+      if (p0 >= L) continue;
+      Pack<E, VEC> pk;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pk.v[e] = my[r][e] >= 0 ? row[my[r][e]] : E(0);
+      if (VEC_STORE) {
+        *reinterpret_cast<Pack<E, VEC>*>(orow + p0) = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (p0 + e < L) orow[p0 + e] = pk.v[e];
+      }
+    }
+  }
+}
+
+static int gather_mode_override() {  // 0 auto, 1 lds, 2 direct -- benchmarking aid, read once
+  static int mode = -1;
+  if (mode < 0) {
+    const char* s = getenv("V3D_GATHER_MODE");
+    mode = 0;
+    if (s && s[0] == 'l') mode = 1;
+    if (s && s[0] == 'd') mode = 2;
+  }
+  return mode;
+}
+
+template <typename E, int VEC>
+static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, int B, int C, int N, int64_t L,
+                             hipStream_t stream) {
+  const E* src = static_cast<const E*>(src_);
+  E* out = static_cast<E*>(out_);
+  const bool vec_store = (L % VEC == 0) && ((uintptr_t)out % (sizeof(E) * VEC) == 0);
+  const size_t row_bytes = align_up((size_t)N * sizeof(E), 16);
+  const int row_vec_ok = ((size_t)N * sizeof(E) % 16 == 0) && ((uintptr_t)src % 16 == 0);
+  // positions per workgroup: R vectors of VEC per thread
+  constexpr int R_BIG = 8, R_SMALL = 2;
+  const bool big = L >= (int64_t)kGatherThreads * VEC * R_BIG;
+  const int R = big ? R_BIG : R_SMALL;
+  const int64_t xblocks = ceil_div(L, (int64_t)kGatherThreads * VEC * R);
+  // channel tile: as large as possible (index reuse, staging amortisation) while keeping >= ~2048 workgroups
+  int CT = 16;
+  while (CT > 2 && xblocks * ceil_div(C, CT) * B < 2048) CT >>= 1;
+  if (CT > C) CT = C;
+  int mode = gather_mode_override();
+  bool use_lds = row_bytes <= 32768 && (int64_t)N * 2 <= (int64_t)kGatherThreads * VEC * R * CT;
+  if (mode == 1) use_lds = row_bytes <= 32768;
+  if (mode == 2) use_lds = false;
+  dim3 grid((unsigned)xblocks, (unsigned)ceil_div(C, CT), (unsigned)B);
+  dim3 block(kGatherThreads);
+#define V3D_LAUNCH_GF(RR, VS)                                                                              \
+  do {                                                                                                     \
+    if (use_lds)                                                                                           \
+      hipLaunchKernelGGL((gather_fwd_lds_kernel<E, VEC, RR, VS>), grid, block, 2 * row_bytes, stream, src, \
+                         idx, out, C, N, L, CT, row_vec_ok);                                               \
+    else                                                                                                   \
+      hipLaunchKernelGGL((gather_fwd_direct_kernel<E, VEC, RR, VS>), grid, block, 0, stream, src, idx,     \
+                         out, C, N, L, CT);                                                                \
+  } while (0)
+  if (big) {
+    if (vec_store) V3D_LAUNCH_GF(R_BIG, true); else V3D_LAUNCH_GF(R_BIG, false);
+  } else {
+    if (vec_store) V3D_LAUNCH_GF(R_SMALL, true); else V3D_LAUNCH_GF(R_SMALL, false);
+  }
+#undef V3D_LAUNCH_GF
+  return launch_status("gather_forward");
+}
+
+static int gather_fwd_dispatch(const char* what, const void* src, const int64_t* idx, void* out, int B, int C,
+                               int N, int64_t L, int elem, int device, void* stream_) {
+  V3D_REQUIRE(B >= 0 && C >= 0 && N >= 0 && L >= 0, what, "negative dimension");
+  V3D_REQUIRE(elem == 1 || elem == 2 || elem == 4 || elem == 8, what, "elem_bytes must be 1, 2, 4 or 8");
+  if (B == 0 || C == 0 || L == 0) return 0;
+  V3D_REQUIRE(src && idx && out, what, "null pointer");
+  if (B > kMaxGridYZ || L > (int64_t)INT32_MAX) {
+    set_last_error("%s: B <= 65535 and targets per cloud < 2^31 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  switch (elem) {
+    case 1: return launch_gather_fwd<uint8_t, 4>(src, idx, out, B, C, N, L, stream);
+    case 2: return launch_gather_fwd<uint16_t, 4>(src, idx, out, B, C, N, L, stream);
+    case 4: return launch_gather_fwd<uint32_t, 4>(src, idx, out, B, C, N, L, stream);
+    default: return launch_gather_fwd<uint64_t, 2>(src, idx, out, B, C, N, L, stream);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward: CSR inversion of the index tensor + per-(b,c,n) ordered segment sums
+// ------------------------------------------------------------------------------------------------------
+struct ScatterWorkspace {
+  int32_t* offsets;   // [B][N+1]  exclusive prefix of per-source counts
+  int32_t* cursor;    // [B][N]    counts, then fill cursors
+  int32_t* unsorted;  // [B][L]    target positions grouped by source, arbitrary order inside a group
+  int32_t* sorted;    // [B][L]    ascending inside every group
+  size_t bytes;
+};
+
+static ScatterWorkspace carve_workspace(void* base, int B, int N, int64_t L) {
+  ScatterWorkspace w;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    void* p = base ? static_cast<char*>(base) + off : nullptr;
+    off += align_up(n, 256);
+    return static_cast<int32_t*>(p);
+  };
+  w.offsets = take(sizeof(int32_t) * (size_t)B * ((size_t)N + 1));
+  w.cursor = take(sizeof(int32_t) * (size_t)B * (size_t)N);
+  w.unsorted = take(sizeof(int32_t) * (size_t)B * (size_t)L);
+  w.sorted = take(sizeof(int32_t) * (size_t)B * (size_t)L);
+  w.bytes = off;
+  return w;
+}
+
+__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ idx, int32_t* cursor, int N,
+                                                        int64_t L) {
+  const int b = blockIdx.y;
+  const int64_t* bidx = idx + (int64_t)b * L;
+  int32_t* cur = cursor + (int64_t)b * N;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L; p += (int64_t)gridDim.x * blockDim.x) {
+    int key = (int)bidx[p];
+    if (key >= 0 && key < N) atomicAdd(&cur[key], 1);
+  }
+}
+
+// One workgroup per cloud: exclusive scan of the counts, and reset of the cursors for the fill pass.
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* cursor, int32_t* offsets, int N) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int b = blockIdx.x;
+  int32_t* cur = cursor + (int64_t)b * N;
+  int32_t* off = offsets + (int64_t)b * (N + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    int i = base + tid;
+    int v = i < N ? cur[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
+    int carry = carry_s;
+    if (i < N) {
+      off[i] = carry + wave_base + incl - v;
+      cur[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wave_base + incl;
+    __syncthreads();
+  }
+  if (tid == 0) off[N] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict__ idx,
+                                                       const int32_t* __restrict__ offsets, int32_t* cursor,
+                                                       int32_t* unsorted, int N, int64_t L) {
+  const int b = blockIdx.y;
+  const int64_t* bidx = idx + (int64_t)b * L;
+  const int32_t* off = offsets + (int64_t)b * (N + 1);
+  int32_t* cur = cursor + (int64_t)b * N;
+  int32_t* uns = unsorted + (int64_t)b * L;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L; p += (int64_t)gridDim.x * blockDim.x) {
+    int key = (int)bidx[p];
+    if (key >= 0 && key < N) {
+      int slot = off[key] + atomicAdd(&cur[key], 1);
+      uns[slot] = (int32_t)p;
+    }
+  }
+}
+
+// Rank sort inside every group: positions are distinct, so rank = number of smaller members.
+__global__ __launch_bounds__(256) void csr_rank_kernel(const int64_t* __restrict__ idx,
+                                                       const int32_t* __restrict__ offsets,
+                                                       const int32_t* __restrict__ unsorted, int32_t* sorted,
+                                                       int N, int64_t L) {
+  const int b = blockIdx.y;
+  const int64_t* bidx = idx + (int64_t)b * L;
+  const int32_t* off = offsets + (int64_t)b * (N + 1);
+  const int32_t* uns = unsorted + (int64_t)b * L;
+  int32_t* srt = sorted + (int64_t)b * L;
+  const int filled = off[N];
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < filled;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    int e = uns[s];
+    int key = (int)bidx[e];
+    int start = off[key], end = off[key + 1];
+    int rank = 0;
+    for (int j = start; j < end; ++j) rank += (uns[j] < e) ? 1 : 0;
+    srt[start + rank] = e;
+  }
+}
+
+// MODE 0: value(t) = gout[row + t]                       (gather / group_gather backward)
+// MODE 1: value(t) = gout[row + t/3] * w[b][t]           (three_interpolate backward, product rounded first)
+template <typename T, int MODE, int CT>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const T* __restrict__ gout, const T* __restrict__ w,
+                                                          const int32_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ sorted, T* __restrict__ gsrc,
+                                                          int C, int N, int64_t L, int64_t Lrow) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CT;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int32_t* off = offsets + (int64_t)b * (N + 1);
+  const int32_t* srt = sorted + (int64_t)b * L;
+  const T* wb = MODE == 1 ? w + (int64_t)b * L : nullptr;
+  const int start = off[n], end = off[n + 1];
+  T acc[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) acc[i] = T(0);
+  const T* g0 = gout + ((int64_t)b * C + c0) * Lrow;
+  for (int j = start; j < end; ++j) {
+    int t = srt[j];
+    int64_t col = MODE == 1 ? (int64_t)(t / 3) : (int64_t)t;
+    T wt = MODE == 1 ? wb[t] : T(1);
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      if (c0 + i < C) {
+        T v = g0[(int64_t)i * Lrow + col];
+        if (MODE == 1) v = v * wt;
+        acc[i] = acc[i] + v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+    if (c0 + i < C) gsrc[((int64_t)b * C + c0 + i) * N + n] = acc[i];
+}
+
+template <typename T, int MODE>
+static int scatter_backward(const char* what, const T* gout, const int64_t* idx, const T* w, T* gsrc, int B, int C,
+                            int N, int64_t L, void* workspace, size_t workspace_bytes, int device, void* stream_) {
+  V3D_REQUIRE(B >= 0 && C >= 0 && N >= 0 && L >= 0, what, "negative dimension");
+  if (B == 0 || C == 0 || N == 0) return 0;
+  V3D_REQUIRE(gsrc && (L == 0 || (gout && idx)) && (MODE == 0 || L == 0 || w), what, "null pointer");
+  if (B > kMaxGridYZ || L > (int64_t)INT32_MAX) {
+    set_last_error("%s: B <= 65535 and targets per cloud < 2^31 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (L == 0) {
+    V3D_HIP_TRY(hipMemsetAsync(gsrc, 0, sizeof(T) * (size_t)B * C * N, stream), what);
+    return 0;
+  }
+  const size_t need = carve_workspace(nullptr, B, N, L).bytes;
+  void* base = workspace;
+  bool own = false;
+  if (base == nullptr) {
+    V3D_HIP_TRY(hipMallocAsync(&base, need, stream), what);
+    own = true;
+  } else if (workspace_bytes < need || ((uintptr_t)base & 255) != 0) {
+    set_last_error("%s: workspace needs %zu bytes, 256-B aligned (got %zu)", what, need, workspace_bytes);
+    return V3D_ERR_WORKSPACE;
+  }
+  ScatterWorkspace ws = carve_workspace(base, B, N, L);
+  int rc = 0;
+  do {
+    hipError_t e = hipMemsetAsync(ws.cursor, 0, sizeof(int32_t) * (size_t)B * N, stream);
+    if (e != hipSuccess) {
+      set_last_error("%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
+      rc = (int)e;
+      break;
+    }
+    const unsigned xb = (unsigned)std::min<int64_t>(ceil_div(L, 256), 1024);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.cursor, N, L);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, stream, ws.cursor, ws.offsets, N);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.cursor,
+                       ws.unsorted, N, L);
+    hipLaunchKernelGGL(csr_rank_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.unsorted,
+                       ws.sorted, N, L);
+    constexpr int CT = 8;
+    const int64_t Lrow = MODE == 1 ? L / 3 : L;
+    dim3 grid((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, CT), (unsigned)B);
+    hipLaunchKernelGGL((segment_sum_kernel<T, MODE, CT>), grid, dim3(256), 0, stream, gout, w, ws.offsets,
+                       ws.sorted, gsrc, C, N, L, Lrow);
+    rc = launch_status(what);
+  } while (0);
+  if (own) {
+    hipError_t e = hipFreeAsync(base, stream);
+    if (rc == 0 && e != hipSuccess) {
+      set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
+      rc = (int)e;
+    }
+  }
+  return rc;
+}
+
+// used by interp.hip
+int three_interp_bwd_f32_impl(const float* gout, const int64_t* idx, const float* w, float* gsrc, int B, int C,
+                              int S, int Q, void* ws, size_t wsb, int device, void* stream) {
+  return scatter_backward<float, 1>("three_interpolate_backward", gout, idx, w, gsrc, B, C, S, (int64_t)Q * 3, ws,
+                                    wsb, device, stream);
+}
+int three_interp_bwd_f64_impl(const double* gout, const int64_t* idx, const double* w, double* gsrc, int B, int C,
+                              int S, int Q, void* ws, size_t wsb, int device, void* stream) {
+  return scatter_backward<double, 1>("three_interpolate_backward", gout, idx, w, gsrc, B, C, S, (int64_t)Q * 3, ws,
+                                     wsb, device, stream);
+}
+
+}  // namespace v3d
+
+extern "C" {
+
+size_t v3d_scatter_workspace_bytes(int B, int num_sources, int64_t positions_per_batch) {
+  if (B <= 0 || num_sources < 0 || positions_per_batch < 0) return 0;
+  return v3d::carve_workspace(nullptr, B, num_sources, positions_per_batch).bytes;
+}
+
+int v3d_gather_fwd(const void* sources, const int64_t* indices, void* targets, int B, int C, int N, int M,
+                   int elem_bytes, int device, void* stream) {
+  return v3d::gather_fwd_dispatch("gather_forward", sources, indices, targets, B, C, N, (int64_t)M, elem_bytes,
+                                  device, stream);
+}
+
+int v3d_group_gather_fwd(const void* sources, const int64_t* indices, void* targets, int B, int C, int N, int M,
+                         int K, int elem_bytes, int device, void* stream) {
+  if (M < 0 || K < 0) return v3d::invalid("group_gather_forward", "negative dimension");
+  return v3d::gather_fwd_dispatch("group_gather_forward", sources, indices, targets, B, C, N, (int64_t)M * K,
+                                  elem_bytes, device, stream);
+}
+
+int v3d_gather_bwd_f32(const float* g, const int64_t* idx, float* gs, int B, int C, int N, int M, void* ws,
+                       size_t wsb, int device, void* stream) {
+  return v3d::scatter_backward<float, 0>("gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M, ws, wsb,
+                                         device, stream);
+}
+int v3d_gather_bwd_f64(const double* g, const int64_t* idx, double* gs, int B, int C, int N, int M, void* ws,
+                       size_t wsb, int device, void* stream) {
+  return v3d::scatter_backward<double, 0>("gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M, ws, wsb,
+                                          device, stream);
+}
+int v3d_group_gather_bwd_f32(const float* g, const int64_t* idx, float* gs, int B, int C, int N, int M, int K,
+                             void* ws, size_t wsb, int device, void* stream) {
+  if (M < 0 || K < 0) return v3d::invalid("group_gather_backward", "negative dimension");
+  return v3d::scatter_backward<float, 0>("group_gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M * K,
+                                         ws, wsb, device, stream);
+}
+int v3d_group_gather_bwd_f64(const double* g, const int64_t* idx, double* gs, int B, int C, int N, int M, int K,
+                             void* ws, size_t wsb, int device, void* stream) {
+  if (M < 0 || K < 0) return v3d::invalid("group_gather_backward", "negative dimension");
+  return v3d::scatter_backward<double, 0>("group_gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M * K,
+                                          ws, wsb, device, stream);
+}
+
+}  // extern "C"

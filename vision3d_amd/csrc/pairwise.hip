@@ -1,0 +1,439 @@
+// pairwise.hip -- feature-space pairwise distance on fp32-input MFMA, row top-k selection, and the
+// partial-top-k merge used by reference-set sharding.
+// Semantics: ops/pairwise_distance.py:39-56 (expansion branch) and the call-site semantics of
+// ops/knn.py:10-27 (pykeops Kmin_argKmin of the Euclidean norm; third-party, see DESIGN.md "parity unpinned").
+//
+// pairwise kernel: out[b,n,m] = clamp((x2[n] - 2*xy[n,m]) + y2[m], 0), xy on v_mfma_f32_32x32x2_f32 (exact fp32
+// FMA chain in k order -- bf16/fp8 MFMA cannot hold the 1e-5 bar, MI355X has no TF32).  128x128 output tile per
+// 256-thread workgroup, 64x64 per wave (2x2 MFMA tiles, 64 accumulator VGPRs), K staged through LDS in 32-deep
+// steps, tiles stored k-major ([k][row]) so an operand fragment is one conflict-free ds_read_b32.  Row/column
+// squared norms are accumulated from the same LDS tiles and applied with clamp / sqrt in the epilogue, so the
+// N x M matrix is written exactly once (the reference makes 3-4 elementwise passes over it).
+#include <math.h>
+
+#include "common.h"
+
+namespace v3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PD_BM = 128, PD_BN = 128, PD_BK = 32, PD_THREADS = 256;
+constexpr int PD_LD = PD_BM + 4;  // padded leading dimension of the k-major LDS tiles
+
+// Loads a (128 rows x 32 k) slab of a row-major (rows x C) matrix into LDS, transposed to [k][row].
+__device__ __forceinline__ void pd_stage(const float* __restrict__ base, int rows, int C, int row0, int k0,
+                                         bool vec_ok, float* lds) {
+  // 128 rows x 8 float4 per row = 1024 float4; 256 threads x 4
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    int f = it * PD_THREADS + threadIdx.x;
+    int r = f >> 3, k4 = (f & 7) * 4;
+    int row = row0 + r, k = k0 + k4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+      const float* p = base + (int64_t)row * C + k;
+      if (vec_ok && k + 3 < C) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < C) v[e] = p[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lds[(k4 + e) * PD_LD + r] = v[e];
+  }
+}
+
+// STRICT: the exact difference form sum_c (x_c - y_c)^2 (pairwise_distance.py:28-37) on the VALU, accumulated in
+// the same per-lane output layout as the MFMA path so both share staging and epilogue.
+template <bool STRICT>
+__global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ y,
+                                                                       float* __restrict__ out, int N, int M, int C,
+                                                                       int64_t y_batch_stride, int64_t out_ld,
+                                                                       int flags, float eps, int vec_ok) {
+  __shared__ float xs[PD_BK * PD_LD];
+  __shared__ float ys[PD_BK * PD_LD];
+  __shared__ float x2s[PD_BM];
+  __shared__ float y2s[PD_BN];
+  const int b = blockIdx.z;
+  const int row0 = blockIdx.y * PD_BM, col0 = blockIdx.x * PD_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
+  const float* xb = x + (int64_t)b * N * C;
+  const float* yb = y + (int64_t)b * y_batch_stride;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float norm = 0.f;  // threads 0..127: x row `tid`; 128..255: y row `tid-128`
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int k0 = 0; k0 < C; k0 += PD_BK) {
+    __syncthreads();
+    pd_stage(xb, N, C, row0, k0, vec_ok, xs);
+    pd_stage(yb, M, C, col0, k0, vec_ok, ys);
+    __syncthreads();
+    if (STRICT) {
+      for (int k = 0; k < PD_BK; ++k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float yv = ys[k * PD_LD + wc * 64 + j * 32 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float xv = xs[k * PD_LD + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+              const float df = xv - yv;
+              acc[i][j][r] = __builtin_fmaf(df, df, acc[i][j][r]);
+            }
+          }
+        }
+      }
+      continue;
+    }
+    {
+      const float* t = tid < 128 ? xs : ys;
+      const int r = tid & 127;
+#pragma unroll
+      for (int k = 0; k < PD_BK; ++k) {
+        float v = t[k * PD_LD + r];
+        norm = __builtin_fmaf(v, v, norm);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < PD_BK; kk += 2) {
+      float a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = xs[(kk + lh) * PD_LD + wr * 64 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[j] = ys[(kk + lh) * PD_LD + wc * 64 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  if (tid < 128) x2s[tid] = norm; else y2s[tid - 128] = norm;
+  __syncthreads();
+
+  const bool normalized = flags & V3D_PD_NORMALIZED;
+  const bool do_sqrt = flags & V3D_PD_SQRT;
+  float* ob = out + (int64_t)b * N * out_ld;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cl = wc * 64 + j * 32 + l31;
+      const int col = col0 + cl;
+      const float y2 = y2s[cl];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = row0 + rl;
+        const float xy = acc[i][j][r];
+        float d;
+        if (STRICT) {
+          d = do_sqrt ? sqrtf(xy) : xy;  // :34-37 (norm, then optional square): no eps, no clamp
+        } else {
+          d = normalized ? (2.0f - 2.0f * xy) : ((x2s[rl] - 2.0f * xy) + y2);  // pairwise_distance.py:47,:51
+          d = fmaxf(d, 0.0f);                                                   // :53
+          if (do_sqrt) d = sqrtf(d + eps);                                      // :56
+        }
+        if (row < N && col < M) ob[(int64_t)row * out_ld + col] = d;
+      }
+    }
+  }
+}
+
+static int launch_pairwise(const float* x, const float* y, float* out, int batch, int N, int M, int C,
+                           int64_t out_ld, int flags, float eps, hipStream_t stream) {
+  const int vec_ok = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+  dim3 grid((unsigned)ceil_div(M, PD_BN), (unsigned)ceil_div(N, PD_BM), (unsigned)batch);
+  if (flags & V3D_PD_STRICT)
+    hipLaunchKernelGGL(pairwise_distance_kernel<true>, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C,
+                       (int64_t)M * C, out_ld, flags, eps, vec_ok);
+  else
+    hipLaunchKernelGGL(pairwise_distance_kernel<false>, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C,
+                       (int64_t)M * C, out_ld, flags, eps, vec_ok);
+  return launch_status("pairwise_distance");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// row top-k over a materialised distance chunk: one wave per row, the running list (ascending by
+// (distance, index), k <= 64) lives one entry per lane; candidates are inserted with a whole-wave shift.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_shr1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ D, int64_t rows, int ncols,
+                                                        int64_t ld, int col_base, int k, int first_chunk,
+                                                        float* __restrict__ run_d, int* __restrict__ run_i) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float ld_ = INFINITY;
+  int li = -1;
+  if (!first_chunk && lane < k) {
+    ld_ = run_d[row * k + lane];
+    li = run_i[row * k + lane];
+  }
+  float tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1));
+  const float* drow = D + row * ld;
+  for (int c0 = 0; c0 < ncols; c0 += 64) {
+    const int c = c0 + lane;
+    const float d = c < ncols ? drow[c] : INFINITY;
+    unsigned long long m = __ballot(d < tau);
+    while (m) {
+      const int l = __builtin_ffsll((long long)m) - 1;
+      const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
+      const int ci = col_base + c0 + l;
+      // entries <= cd stay (equal distances: earlier index first); the rest shift one lane up
+      const unsigned long long keep = __ballot(ld_ <= cd);
+      const int pos = __builtin_popcountll(keep);
+      const float sd = wave_shr1(ld_);
+      const int si = wave_shr1(li);
+      if (lane > pos) {
+        ld_ = sd;
+        li = si;
+      } else if (lane == pos) {
+        ld_ = cd;
+        li = ci;
+      }
+      tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1));
+      m = __ballot(d < tau) & ~((2ull << l) - 1ull);
+    }
+  }
+  if (lane < k) {
+    run_d[row * k + lane] = ld_;
+    run_i[row * k + lane] = li;
+  }
+}
+
+// Final pass: recompute the k selected distances exactly as sqrt(sum_c (x_c - y_c)^2) (what pykeops evaluates,
+// ops/knn.py:25), re-rank by (distance, index) and write fp32 distances + int64 (offset) indices.
+__global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ run_d,
+                                                                const int* __restrict__ run_i, int batch, int N, int M,
+                                                                int C, int k, int64_t index_offset,
+                                                                float* __restrict__ out_d, int64_t* __restrict__ out_i) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)batch * N) return;
+  const int b = (int)(row / N);
+  int idx = lane < k ? run_i[row * k + lane] : -1;
+  float dist = INFINITY;
+  if (idx >= 0) {
+    const float* xr = x + row * C;
+    const float* yr = y + ((int64_t)b * M + idx) * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float df = xr[c] - yr[c];
+      acc = __builtin_fmaf(df, df, acc);
+    }
+    dist = sqrtf(acc);
+  }
+  // rank sort among the k entries (k <= 64): position = number of entries that precede mine
+  int rank = 0;
+  for (int j = 0; j < k; ++j) {
+    const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dist), j));
+    const int ij = __builtin_amdgcn_readlane(idx, j);
+    const bool before = (ij >= 0) && (idx < 0 || dj < dist || (dj == dist && ij < idx));
+    rank += before ? 1 : 0;
+  }
+  if (lane < k) {
+    // unfilled entries (M < k) all tie: keep them behind the real ones in lane order
+    if (idx < 0) {
+      const unsigned long long empties = __ballot(idx < 0 && lane < k);
+      const int filled = k - __builtin_popcountll(empties);
+      rank = filled + __builtin_popcountll(empties & ((1ull << lane) - 1ull));
+    }
+    out_d[row * k + rank] = dist;
+    out_i[row * k + rank] = idx >= 0 ? (int64_t)idx + index_offset : (int64_t)-1;
+  }
+}
+
+// Merge of G partial lists per row: parts (G, rows, k) sorted ascending -> (rows, k) by (distance, index).
+// One wave per row; lane j repeatedly... k <= 64 and G*k candidates: rank every candidate against all others.
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pd, const int64_t* __restrict__ pi,
+                                                         float* __restrict__ od, int64_t* __restrict__ oi, int G,
+                                                         int64_t rows, int k) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int total = G * k;
+  for (int c = lane; c < total; c += 64) {
+    const int g = c / k, j = c % k;
+    const float d = pd[((int64_t)g * rows + row) * k + j];
+    const int64_t id = pi[((int64_t)g * rows + row) * k + j];
+    int rank = 0;
+    for (int o = 0; o < total; ++o) {
+      const int go = o / k, jo = o % k;
+      const float d2 = pd[((int64_t)go * rows + row) * k + jo];
+      const int64_t i2 = pi[((int64_t)go * rows + row) * k + jo];
+      // invalid entries (index < 0) sort last; full order (distance, index, slot) so ranks are distinct
+      const bool v1 = id >= 0, v2 = i2 >= 0;
+      bool before;
+      if (v1 != v2) before = v2;
+      else if (d2 != d) before = d2 < d;
+      else if (i2 != id) before = i2 < id;
+      else before = o < c;
+      rank += before ? 1 : 0;
+    }
+    if (rank < k) {
+      od[row * k + rank] = d;
+      oi[row * k + rank] = id;
+    }
+  }
+}
+
+struct KnnFeatWorkspace {
+  float* chunk;  // (batch*N, MC)
+  float* run_d;  // (batch*N, k)
+  int* run_i;    // (batch*N, k)
+  int mc;
+  size_t bytes;
+};
+
+static KnnFeatWorkspace carve_knn_ws(void* base, int batch, int N, int M, int k) {
+  KnnFeatWorkspace w;
+  const int64_t rows = (int64_t)batch * N;
+  // chunk of columns sized to stay inside the 256 MiB Infinity Cache (<= 128 MiB), multiple of the 128 tile
+  int64_t mc = (128ll << 20) / (rows * 4);
+  mc = mc / 128 * 128;
+  if (mc < 128) mc = 128;
+  const int64_t m_pad = ceil_div(M, 128) * 128;
+  if (mc > m_pad) mc = m_pad;
+  w.mc = (int)mc;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    void* p = base ? static_cast<char*>(base) + off : nullptr;
+    off += align_up(n, 256);
+    return p;
+  };
+  w.chunk = static_cast<float*>(take(sizeof(float) * (size_t)rows * (size_t)mc));
+  w.run_d = static_cast<float*>(take(sizeof(float) * (size_t)rows * (size_t)k));
+  w.run_i = static_cast<int*>(take(sizeof(int) * (size_t)rows * (size_t)k));
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace v3d
+
+extern "C" {
+
+int v3d_pairwise_distance_f32(const float* x, const float* y, float* out, int batch, int N, int M, int C, int flags,
+                              float eps, int device, void* stream_) {
+  using namespace v3d;
+  const char* what = "pairwise_distance";
+  V3D_REQUIRE(batch >= 0 && N >= 0 && M >= 0 && C >= 0, what, "negative dimension");
+  if (batch == 0 || N == 0 || M == 0) return 0;
+  V3D_REQUIRE(x && y && out, what, "null pointer");
+  if (batch > kMaxGridYZ || ceil_div(N, PD_BM) > kMaxGridYZ) {
+    set_last_error("%s: batch <= 65535 and N <= 8388480 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  return launch_pairwise(x, y, out, batch, N, M, C, (int64_t)M, flags, eps, static_cast<hipStream_t>(stream_));
+}
+
+size_t v3d_knn_feat_workspace_bytes(int batch, int N, int M, int C, int k) {
+  (void)C;
+  if (batch <= 0 || N <= 0 || M <= 0 || k <= 0) return 0;
+  return v3d::carve_knn_ws(nullptr, batch, N, M, k).bytes;
+}
+
+int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* indices, int batch, int N, int M,
+                     int C, int k, int64_t index_offset, void* workspace, size_t workspace_bytes, int device,
+                     void* stream_) {
+  using namespace v3d;
+  const char* what = "knn_feat";
+  V3D_REQUIRE(batch >= 0 && N >= 0 && M >= 0 && C >= 0 && k >= 0, what, "negative dimension");
+  V3D_REQUIRE(k <= 64, what, "k must be <= 64");
+  if (batch == 0 || N == 0 || k == 0) return 0;
+  V3D_REQUIRE(x && distances && indices && (M == 0 || y), what, "null pointer");
+  if (batch > kMaxGridYZ || ceil_div(N, PD_BM) > kMaxGridYZ) {
+    set_last_error("%s: batch <= 65535 and N <= 8388480 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t rows = (int64_t)batch * N;
+  const int Mw = M > 0 ? M : 1;
+  const size_t need = carve_knn_ws(nullptr, batch, N, Mw, k).bytes;
+  void* base = workspace;
+  bool own = false;
+  if (base == nullptr) {
+    V3D_HIP_TRY(hipMallocAsync(&base, need, stream), what);
+    own = true;
+  } else if (workspace_bytes < need || ((uintptr_t)base & 255) != 0) {
+    set_last_error("%s: workspace needs %zu bytes, 256-B aligned (got %zu)", what, need, workspace_bytes);
+    return V3D_ERR_WORKSPACE;
+  }
+  KnnFeatWorkspace ws = carve_knn_ws(base, batch, N, Mw, k);
+  int rc = 0;
+  const unsigned row_blocks = (unsigned)ceil_div(rows, 4);
+  if (M == 0) {
+    // no candidates: every slot is (inf, -1)
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(row_blocks), dim3(256), 0, stream, ws.chunk, rows, 0, (int64_t)ws.mc, 0,
+                       k, 1, ws.run_d, ws.run_i);
+  }
+  for (int m0 = 0; m0 < M && rc == 0; m0 += ws.mc) {
+    const int mc = std::min(ws.mc, M - m0);
+    // distances of every row of every batch against columns [m0, m0+mc): batch b uses y + (b*M + m0)*C
+    const float* ychunk = y + (int64_t)m0 * C;
+    {
+      const int vec_ok = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)ychunk % 16 == 0);
+      dim3 grid((unsigned)ceil_div(mc, PD_BN), (unsigned)ceil_div(N, PD_BM), (unsigned)batch);
+      // only mc columns are visited per cloud, but consecutive clouds of y stay M*C apart
+      hipLaunchKernelGGL(pairwise_distance_kernel<false>, grid, dim3(PD_THREADS), 0, stream, x, ychunk, ws.chunk, N, mc, C,
+                         (int64_t)M * C, (int64_t)ws.mc, 0, 0.f, vec_ok);
+      rc = launch_status(what);
+    }
+    if (rc) break;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(row_blocks), dim3(256), 0, stream, ws.chunk, rows, mc, (int64_t)ws.mc,
+                       m0, k, m0 == 0 ? 1 : 0, ws.run_d, ws.run_i);
+    rc = launch_status(what);
+  }
+  if (rc == 0) {
+    hipLaunchKernelGGL(knn_feat_finalize_kernel, dim3(row_blocks), dim3(256), 0, stream, x, y, ws.run_d, ws.run_i,
+                       batch, N, Mw, C, k, index_offset, distances, indices);
+    rc = launch_status(what);
+  }
+  if (own) {
+    hipError_t e = hipFreeAsync(base, stream);
+    if (rc == 0 && e != hipSuccess) {
+      set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
+      rc = (int)e;
+    }
+  }
+  return rc;
+}
+
+int v3d_topk_merge_f32(const float* parts_dist, const int64_t* parts_idx, float* out_dist, int64_t* out_idx, int G,
+                       int64_t rows, int k, int device, void* stream_) {
+  using namespace v3d;
+  const char* what = "topk_merge";
+  V3D_REQUIRE(G >= 1 && rows >= 0 && k >= 0, what, "bad dimension");
+  if (rows == 0 || k == 0) return 0;
+  V3D_REQUIRE(parts_dist && parts_idx && out_dist && out_idx, what, "null pointer");
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, stream, parts_dist, parts_idx,
+                     out_dist, out_idx, G, rows, k);
+  return launch_status(what);
+}
+
+}  // extern "C"

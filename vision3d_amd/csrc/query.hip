@@ -1,0 +1,454 @@
+// query.hip -- brute-force neighbour queries on 3-D points: ball_query, three_nn, knn_points.
+// Semantics: ball_query_cuda.cuh:11-55, three_nn_cuda.cuh:11-75, knn_points_cuda.cuh:9-93 of the reference.
+// Design (gfx950): support points of one cloud are staged once per workgroup in LDS and shared by all its
+// queries; all three kernels are VALU/latency bound (a few MB of I/O against 10^8 pair evaluations).
+//   * ball_query : one WAVE per group of G queries.  The 64 lanes test 64 consecutive supports at once; a
+//                  ballot + prefix popcount gives every hit its slot in INDEX ORDER, so the "first k in scan
+//                  order" rule of the reference is kept while hits are stored coalesced; a wave stops as soon
+//                  as its queries are full.
+//   * three_nn   : one thread per query, supports broadcast from LDS as 16-byte points, branch-free
+//                  strict-< insertion cascade (ties keep the lower index first, like the reference).
+//   * knn_points : one wave per query.  Lanes evaluate 64 supports at a time and ballot those that beat the
+//                  heap root; only those are replayed, in index order, through the reference's max-heap
+//                  (kept in LDS, sifted by the whole wave with uniform addresses), so ties leave the heap in
+//                  exactly the reference's order.
+// Squared distances use the reference's expression order with one rounding per operation (the library is
+// compiled with -ffp-contract=off).
+#include <type_traits>
+
+#include "common.h"
+
+namespace v3d {
+
+constexpr int kQueryThreads = 256;
+constexpr int kWavesPerBlock = kQueryThreads / kWave;
+
+template <typename T>
+__device__ __forceinline__ T sq_dist(T qx, T qy, T qz, T sx, T sy, T sz) {
+  T dx = qx - sx, dy = qy - sy, dz = qz - sz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ __forceinline__ float read_lane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  long long bits = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), lane);
+  int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Cooperative copy of `count` support points (AoS, 3*T each) of one cloud into LDS, unchanged layout.
+// Lane i later reads words 3i, 3i+1, 3i+2: stride 3 is co-prime with the bank count, so conflict-free.
+template <typename T>
+__device__ __forceinline__ void stage_supports_aos(const T* __restrict__ s_cloud, int first, int count, T* lds) {
+  const T* g = s_cloud + (int64_t)first * 3;
+  for (int i = threadIdx.x; i < count * 3; i += blockDim.x) lds[i] = g[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ball query
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int G, int TS>
+__global__ __launch_bounds__(kQueryThreads) void ball_query_kernel(const T* __restrict__ q, const T* __restrict__ s,
+                                                                   int64_t* __restrict__ out, int M, int N, int k,
+                                                                   T r2) {
+  __shared__ T tile[TS * 3];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q_first = (blockIdx.x * kWavesPerBlock + wave) * G;
+  const T* s_cloud = s + (int64_t)b * N * 3;
+
+  T qx[G], qy[G], qz[G];
+  int cnt[G], first[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    int qi = q_first + g;
+    bool live = qi < M;
+    const T* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
+    qx[g] = qp[0];
+    qy[g] = qp[1];
+    qz[g] = qp[2];
+    cnt[g] = live ? 0 : k;  // dead slots count as full
+    first[g] = -1;
+  }
+
+  for (int t0 = 0; t0 < N; t0 += TS) {
+    const int tcount = min(TS, N - t0);
+    __syncthreads();
+    stage_supports_aos(s_cloud, t0, tcount, tile);
+    __syncthreads();
+    bool all_full = true;
+#pragma unroll
+    for (int g = 0; g < G; ++g) all_full = all_full && (cnt[g] >= k);
+    if (all_full) continue;  // wave-uniform; keep taking part in the barriers
+    for (int c0 = 0; c0 < tcount; c0 += 64) {
+      const int j = c0 + lane;
+      const bool valid = j < tcount;
+      const int jj = valid ? j : 0;
+      const T sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+      bool any_open = false;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (cnt[g] < k) {  // wave-uniform
+          T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
+          bool hit = valid && (d < r2);  // strict, ball_query_cuda.cuh:43
+          unsigned long long m = __ballot(hit);
+          if (m) {
+            int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            int slot = cnt[g] + before;
+            if (hit && slot < k) out[((int64_t)b * M + q_first + g) * k + slot] = (int64_t)(t0 + j);
+            if (first[g] < 0) first[g] = t0 + c0 + (__builtin_ffsll((long long)m) - 1);
+            cnt[g] += __builtin_popcountll(m);
+          }
+          any_open = any_open || (cnt[g] < k);
+        }
+      }
+      if (!any_open) break;
+    }
+  }
+  // A query with 0 < cnt < k repeats its first hit in the remaining slots (ball_query_cuda.cuh:44-48);
+  // cnt == 0 leaves the caller's zero fill untouched.
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (q_first + g < M && cnt[g] > 0 && cnt[g] < k) {
+      int64_t* row = out + ((int64_t)b * M + q_first + g) * k;
+      for (int slot = cnt[g] + lane; slot < k; slot += 64) row[slot] = (int64_t)first[g];
+    }
+  }
+}
+
+template <typename T>
+static int ball_query(const T* q, const T* s, int64_t* out, int B, int M, int N, float max_radius, int k, int device,
+                      void* stream_) {
+  const char* what = "ball_query";
+  V3D_REQUIRE(B >= 0 && M >= 0 && N >= 0 && k >= 0, what, "negative dimension");
+  if (B == 0 || M == 0 || k == 0 || N == 0) return 0;
+  V3D_REQUIRE(q && s && out, what, "null pointer");
+  if (B > kMaxGridYZ) {
+    set_last_error("%s: B <= 65535 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const T r2 = static_cast<T>(max_radius) * static_cast<T>(max_radius);  // ball_query_cuda.cuh:28
+  constexpr int G = 4;
+  constexpr int TS = 2048;
+  dim3 grid((unsigned)ceil_div(M, kWavesPerBlock * G), (unsigned)B), block(kQueryThreads);
+  hipLaunchKernelGGL((ball_query_kernel<T, G, TS>), grid, block, 0, stream, q, s, out, M, N, k, r2);
+  return launch_status(what);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// three_nn
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+struct alignas(sizeof(T) * 4) Point4 {
+  T x, y, z, pad;
+};
+
+template <typename T, int TS>
+__global__ __launch_bounds__(kQueryThreads) void three_nn_kernel(const T* __restrict__ q, const T* __restrict__ s,
+                                                                 T* __restrict__ out_d, int64_t* __restrict__ out_i,
+                                                                 int Q, int S) {
+  __shared__ Point4<T> tile[TS];
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * kQueryThreads + threadIdx.x;
+  const bool live = qi < Q;
+  const T* qp = q + ((int64_t)b * Q + (live ? qi : 0)) * 3;
+  const T qx = qp[0], qy = qp[1], qz = qp[2];
+  const T* s_cloud = s + (int64_t)b * S * 3;
+  // the reference keeps the bests as double 1e40 (three_nn_cuda.cuh:37-39): any finite T compares below it
+  // and +inf / NaN never do -- +inf in T behaves identically under the strict '<'.
+  T b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = -1, i2 = -1, i3 = -1;
+  for (int t0 = 0; t0 < S; t0 += TS) {
+    const int tcount = min(TS, S - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < tcount; i += kQueryThreads) {
+      const T* g = s_cloud + (int64_t)(t0 + i) * 3;
+      Point4<T> p;
+      p.x = g[0];
+      p.y = g[1];
+      p.z = g[2];
+      p.pad = T(0);
+      tile[i] = p;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < tcount; ++j) {
+      const Point4<T> p = tile[j];  // same address in every lane: LDS broadcast
+      const T d = sq_dist(qx, qy, qz, p.x, p.y, p.z);
+      const bool lt1 = d < b1, lt2 = d < b2, lt3 = d < b3;  // b1 <= b2 <= b3 always, so lt1 => lt2 => lt3
+      const int id = t0 + j;
+      b3 = lt2 ? b2 : (lt3 ? d : b3);
+      i3 = lt2 ? i2 : (lt3 ? id : i3);
+      b2 = lt1 ? b1 : (lt2 ? d : b2);
+      i2 = lt1 ? i1 : (lt2 ? id : i2);
+      b1 = lt1 ? d : b1;
+      i1 = lt1 ? id : i1;
+    }
+  }
+  if (live) {
+    // unfilled slots: sqrt(1e40) = 1e20 cast to T, index -1 (three_nn_cuda.cuh:67-73)
+    const T unfilled = static_cast<T>(1e20);
+    T* od = out_d + ((int64_t)b * Q + qi) * 3;
+    int64_t* oi = out_i + ((int64_t)b * Q + qi) * 3;
+    od[0] = i1 >= 0 ? static_cast<T>(sqrt(b1)) : unfilled;
+    od[1] = i2 >= 0 ? static_cast<T>(sqrt(b2)) : unfilled;
+    od[2] = i3 >= 0 ? static_cast<T>(sqrt(b3)) : unfilled;
+    oi[0] = i1;
+    oi[1] = i2;
+    oi[2] = i3;
+  }
+}
+
+template <typename T>
+static int three_nn(const T* q, const T* s, T* od, int64_t* oi, int B, int Q, int S, int device, void* stream_) {
+  const char* what = "three_nn";
+  V3D_REQUIRE(B >= 0 && Q >= 0 && S >= 0, what, "negative dimension");
+  if (B == 0 || Q == 0) return 0;
+  V3D_REQUIRE(q && od && oi && (S == 0 || s), what, "null pointer");
+  if (B > kMaxGridYZ) {
+    set_last_error("%s: B <= 65535 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  constexpr int TS = 1024;
+  dim3 grid((unsigned)ceil_div(Q, kQueryThreads), (unsigned)B), block(kQueryThreads);
+  hipLaunchKernelGGL((three_nn_kernel<T, TS>), grid, block, 0, stream, q, s, od, oi, Q, S);
+  return launch_status(what);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// radius count: thread per query, supports broadcast from LDS (same staging as three_nn)
+// ------------------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(kQueryThreads) void radius_count_kernel(const float* __restrict__ q,
+                                                                     const float* __restrict__ s,
+                                                                     int64_t* __restrict__ counts, int M, int N,
+                                                                     float radius) {
+  __shared__ Point4<float> tile[TS];
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * kQueryThreads + threadIdx.x;
+  const bool live = qi < M;
+  const float* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const float* s_cloud = s + (int64_t)b * N * 3;
+  int cnt = 0;
+  for (int t0 = 0; t0 < N; t0 += TS) {
+    const int tcount = min(TS, N - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < tcount; i += kQueryThreads) {
+      const float* g = s_cloud + (int64_t)(t0 + i) * 3;
+      Point4<float> p;
+      p.x = g[0];
+      p.y = g[1];
+      p.z = g[2];
+      p.pad = 0.f;
+      tile[i] = p;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < tcount; ++j) {
+      const Point4<float> p = tile[j];
+      const float d = sqrtf(sq_dist(qx, qy, qz, p.x, p.y, p.z));
+      cnt += (radius - d > 0.f) ? 1 : 0;  // relu(radius - d).sign()
+    }
+  }
+  if (live) counts[(int64_t)b * M + qi] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// knn_points
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+struct alignas(sizeof(T) * 2) HeapSlot {
+  T d;
+  int i;
+};
+
+// Sift `v` down from the root of a max-heap of `size` slots: knn_points_cuda.cuh:16-28 with the swaps
+// replaced by "move the child up, carry the value" (same final array).  Wave-uniform: every lane runs it on
+// the same LDS addresses and stores the same values (so each lane's own view of the heap stays coherent
+// without relying on another lane's store).
+template <typename T>
+__device__ __forceinline__ void heap_sift(HeapSlot<T>* h, int size, T vd, int vi) {
+  int root = 0, child = 1;
+  while (child < size) {
+    HeapSlot<T> c = h[child];
+    if (child + 1 < size) {
+      HeapSlot<T> c1 = h[child + 1];
+      if (c1.d > c.d) {  // :21 strict
+        c = c1;
+        ++child;
+      }
+    }
+    if (vd > c.d) break;  // :22 strict
+    h[root] = c;
+    root = child;
+    child = root * 2 + 1;
+  }
+  HeapSlot<T> v;
+  v.d = vd;
+  v.i = vi;
+  h[root] = v;
+}
+
+template <typename T, int QPW, int TS>
+__global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __restrict__ q, const T* __restrict__ s,
+                                                                   T* __restrict__ out_d, int64_t* __restrict__ out_i,
+                                                                   int M, int N, int k) {
+  __shared__ T tile[TS * 3];
+  __shared__ HeapSlot<T> heaps[kWavesPerBlock * QPW * V3D_KNN_MAX_K];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q_first = (blockIdx.x * kWavesPerBlock + wave) * QPW;
+  const T* s_cloud = s + (int64_t)b * N * 3;
+  HeapSlot<T>* my_heaps = heaps + wave * QPW * V3D_KNN_MAX_K;
+
+  T qx[QPW], qy[QPW], qz[QPW], root_d[QPW];
+#pragma unroll
+  for (int g = 0; g < QPW; ++g) {
+    int qi = q_first + g;
+    bool live = qi < M;
+    const T* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
+    qx[g] = qp[0];
+    qy[g] = qp[1];
+    qz[g] = qp[2];
+    root_d[g] = live ? static_cast<T>(1e10) : static_cast<T>(-1);  // dead slot: nothing ever beats -1
+    for (int n = lane; n < k; n += 64) {  // knn_points_cuda.cuh:70-73
+      HeapSlot<T> v;
+      v.d = static_cast<T>(1e10);
+      v.i = 0;
+      my_heaps[g * V3D_KNN_MAX_K + n] = v;
+    }
+  }
+
+  for (int t0 = 0; t0 < N; t0 += TS) {
+    const int tcount = min(TS, N - t0);
+    __syncthreads();
+    stage_supports_aos(s_cloud, t0, tcount, tile);
+    __syncthreads();
+    for (int c0 = 0; c0 < tcount; c0 += 64) {
+      const int j = c0 + lane;
+      const bool valid = j < tcount;
+      const int jj = valid ? j : 0;
+      const T sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) {
+        HeapSlot<T>* h = my_heaps + g * V3D_KNN_MAX_K;
+        const T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
+        unsigned long long m = __ballot(valid && d < root_d[g]);  // :80 strict
+        while (m) {  // replay the candidates in index order
+          const int l = __builtin_ffsll((long long)m) - 1;
+          const T dl = read_lane(d, l);
+          heap_sift(h, k, dl, t0 + c0 + l);
+          root_d[g] = h[0].d;
+          const unsigned long long above = ~((2ull << l) - 1ull);
+          m = __ballot(valid && d < root_d[g]) & above;
+        }
+      }
+    }
+  }
+
+  // heap_sort (knn_points_cuda.cuh:30-37) then the coalesced write-out with sqrt (:88-91)
+#pragma unroll
+  for (int g = 0; g < QPW; ++g) {
+    if (q_first + g >= M) continue;
+    HeapSlot<T>* h = my_heaps + g * V3D_KNN_MAX_K;
+    for (int i = k - 1; i > 0; --i) {
+      HeapSlot<T> top = h[0];
+      HeapSlot<T> last = h[i];
+      h[i] = top;
+      heap_sift(h, i, last.d, last.i);
+    }
+    T* od = out_d + ((int64_t)b * M + q_first + g) * k;
+    int64_t* oi = out_i + ((int64_t)b * M + q_first + g) * k;
+    for (int n = lane; n < k; n += 64) {
+      HeapSlot<T> v = h[n];
+      od[n] = sqrt(v.d);
+      oi[n] = (int64_t)v.i;
+    }
+  }
+}
+
+template <typename T>
+static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, int N, int k, int device,
+                      void* stream_) {
+  const char* what = "knn_points";
+  V3D_REQUIRE(B >= 0 && M >= 0 && N >= 0 && k >= 0, what, "negative dimension");
+  if (k > V3D_KNN_MAX_K) {
+    set_last_error("%s: num_neighbors=%d exceeds %d (reference: best_dist[100])", what, k, V3D_KNN_MAX_K);
+    return V3D_ERR_K_TOO_LARGE;
+  }
+  if (B == 0 || M == 0 || k == 0) return 0;
+  V3D_REQUIRE(q && od && oi && (N == 0 || s), what, "null pointer");
+  if (B > kMaxGridYZ) {
+    set_last_error("%s: B <= 65535 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  constexpr int QPW = 4;
+  constexpr int TS = 1024;
+  dim3 grid((unsigned)ceil_div(M, kWavesPerBlock * QPW), (unsigned)B), block(kQueryThreads);
+  hipLaunchKernelGGL((knn_points_kernel<T, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
+  return launch_status(what);
+}
+
+}  // namespace v3d
+
+extern "C" {
+
+int v3d_ball_query_f32(const float* q, const float* s, int64_t* indices, int B, int M, int N, float max_radius, int k,
+                       int device, void* stream) {
+  return v3d::ball_query<float>(q, s, indices, B, M, N, max_radius, k, device, stream);
+}
+int v3d_ball_query_f64(const double* q, const double* s, int64_t* indices, int B, int M, int N, float max_radius,
+                       int k, int device, void* stream) {
+  return v3d::ball_query<double>(q, s, indices, B, M, N, max_radius, k, device, stream);
+}
+int v3d_radius_count_f32(const float* q, const float* s, int64_t* counts, int B, int M, int N, float radius, int device,
+                         void* stream_) {
+  using namespace v3d;
+  const char* what = "radius_count";
+  V3D_REQUIRE(B >= 0 && M >= 0 && N >= 0, what, "negative dimension");
+  if (B == 0 || M == 0) return 0;
+  V3D_REQUIRE(q && counts && (N == 0 || s), what, "null pointer");
+  if (B > kMaxGridYZ) {
+    set_last_error("%s: B <= 65535 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  dim3 grid((unsigned)ceil_div(M, kQueryThreads), (unsigned)B), block(kQueryThreads);
+  hipLaunchKernelGGL((radius_count_kernel<1024>), grid, block, 0, static_cast<hipStream_t>(stream_), q, s, counts, M, N,
+                     radius);
+  return launch_status(what);
+}
+int v3d_knn_points_f32(const float* q, const float* s, float* d, int64_t* i, int B, int M, int N, int k, int device,
+                       void* stream) {
+  return v3d::knn_points<float>(q, s, d, i, B, M, N, k, device, stream);
+}
+int v3d_knn_points_f64(const double* q, const double* s, double* d, int64_t* i, int B, int M, int N, int k, int device,
+                       void* stream) {
+  return v3d::knn_points<double>(q, s, d, i, B, M, N, k, device, stream);
+}
+int v3d_three_nn_f32(const float* q, const float* s, float* d, int64_t* i, int B, int Q, int S, int device,
+                     void* stream) {
+  return v3d::three_nn<float>(q, s, d, i, B, Q, S, device, stream);
+}
+int v3d_three_nn_f64(const double* q, const double* s, double* d, int64_t* i, int B, int Q, int S, int device,
+                     void* stream) {
+  return v3d::three_nn<double>(q, s, d, i, B, Q, S, device, stream);
+}
+
+}  // extern "C"

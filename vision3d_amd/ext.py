@@ -1,0 +1,314 @@
+"""Drop-in for the CUDA half of the reference's ``vision3d.ext`` pybind11 module.
+
+Same function names, positional order and keyword names as ``/root/reference/vision3d/csrc/pybind.cpp:71-158``;
+same contract: the caller pre-allocates every output tensor, the call writes in place, returns ``None``, runs
+asynchronously on the current stream of the tensors' device and validates its arguments with the reference's
+messages (``csrc/common/torch_helper.h:9-23``).  Underneath, each call is one C-ABI call into
+``libv3d_hip.so`` (``include/v3d_hip.h``) -- hand-written gfx950 kernels, no fallback.
+
+``knn`` is an alias of ``knn_points``: the reference's Python wrapper calls ``ext_module.knn``
+(``ops/knn_points.py:36``) although the extension registers ``knn_points`` (``pybind.cpp:150``).
+"""
+import torch
+
+from . import _lib
+
+__all__ = [
+    "ball_query",
+    "furthest_point_sample",
+    "gather_forward",
+    "gather_backward",
+    "group_gather_forward",
+    "group_gather_backward",
+    "three_nn",
+    "three_interpolate_forward",
+    "three_interpolate_backward",
+    "knn_points",
+    "knn",
+    "pairwise_distance",
+    "radius_count",
+    "knn_feat",
+    "topk_merge",
+]
+
+_FLOATING = {torch.float32: "f32", torch.float64: "f64"}
+# AT_DISPATCH_ALL_TYPES_AND(Bool) of gather_cuda.cu:22 / group_gather_cuda.cu:23
+_ALL_AND_BOOL = {
+    torch.uint8: 1, torch.int8: 1, torch.bool: 1, torch.int16: 2, torch.int32: 4, torch.float32: 4,
+    torch.int64: 8, torch.float64: 8,
+}
+_TYPE_NAMES = {torch.float16: "Half", torch.bfloat16: "BFloat16", torch.float32: "Float", torch.float64: "Double",
+               torch.int32: "Int", torch.int64: "Long", torch.int16: "Short", torch.int8: "Char",
+               torch.uint8: "Byte", torch.bool: "Bool"}
+
+
+def _check_cuda_contiguous(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _check_long(t, name):
+    if t.dtype != torch.int64:
+        raise RuntimeError(f"{name} must be an long tensor")
+
+
+def _check_float(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")
+
+
+def _floating_suffix(t, kernel):
+    try:
+        return _FLOATING[t.dtype]
+    except KeyError:
+        raise RuntimeError(f'"{kernel}" not implemented for \'{_TYPE_NAMES.get(t.dtype, t.dtype)}\'') from None
+
+
+def _same_dtype(kernel, ref, *others):
+    for o in others:
+        if o.dtype != ref.dtype:
+            raise RuntimeError(f"{kernel}: expected scalar type {_TYPE_NAMES.get(ref.dtype, ref.dtype)} but found "
+                               f"{_TYPE_NAMES.get(o.dtype, o.dtype)}")
+
+
+def _where(t):
+    """(device index, raw hipStream_t) of the current stream on the tensor's device."""
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return dev, torch.cuda.current_stream(dev).cuda_stream
+
+
+def _workspace(nbytes, like):
+    """Scratch from torch's caching allocator (stream-ordered reuse, no hipMalloc on the hot path)."""
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=like.device)
+
+
+# --------------------------------------------------------------------------------------------------------
+def ball_query(q_points, s_points, indices, max_radius, num_samples):
+    _check_cuda_contiguous(q_points, "q_points")
+    _check_cuda_contiguous(s_points, "s_points")
+    _check_cuda_contiguous(indices, "indices")
+    _check_long(indices, "indices")
+    sfx = _floating_suffix(q_points, "ball_query_kernel")
+    _same_dtype("ball_query", q_points, s_points)
+    B, M, N = q_points.size(0), q_points.size(1), s_points.size(1)
+    dev, stream = _where(q_points)
+    fn = getattr(_lib.lib(), "v3d_ball_query_" + sfx)
+    _lib.check(fn(q_points.data_ptr(), s_points.data_ptr(), indices.data_ptr(), B, M, N, float(max_radius),
+                  int(num_samples), dev, stream), "ball_query")
+
+
+def furthest_point_sample(points, distances, indices, num_samples):
+    _check_cuda_contiguous(points, "points")
+    _check_cuda_contiguous(distances, "distances")
+    _check_cuda_contiguous(indices, "indices")
+    _check_float(points, "points")
+    _check_float(distances, "distances")
+    _check_long(indices, "indices")
+    B, N = points.size(0), points.size(1)
+    dev, stream = _where(points)
+    _lib.check(_lib.lib().v3d_fps_f32(points.data_ptr(), distances.data_ptr(), indices.data_ptr(), B, N,
+                                      int(num_samples), dev, stream), "furthest_point_sample")
+
+
+def _gather_forward(name, kernel, sources, indices, targets, grouped):
+    _check_cuda_contiguous(sources, "sources")
+    _check_cuda_contiguous(indices, "indices")
+    _check_cuda_contiguous(targets, "targets")
+    _check_long(indices, "indices")
+    try:
+        elem = _ALL_AND_BOOL[sources.dtype]
+    except KeyError:
+        raise RuntimeError(f'"{kernel}" not implemented for \'{_TYPE_NAMES.get(sources.dtype, sources.dtype)}\'') from None
+    _same_dtype(name, sources, targets)
+    B, C, N = sources.size(0), sources.size(1), sources.size(2)
+    dev, stream = _where(sources)
+    if grouped:
+        rc = _lib.lib().v3d_group_gather_fwd(sources.data_ptr(), indices.data_ptr(), targets.data_ptr(), B, C, N,
+                                             indices.size(1), indices.size(2), elem, dev, stream)
+    else:
+        rc = _lib.lib().v3d_gather_fwd(sources.data_ptr(), indices.data_ptr(), targets.data_ptr(), B, C, N,
+                                       indices.size(1), elem, dev, stream)
+    _lib.check(rc, name)
+
+
+def gather_forward(sources, indices, targets):
+    _gather_forward("gather_forward", "gather_forward_kernel", sources, indices, targets, grouped=False)
+
+
+def group_gather_forward(sources, indices, targets):
+    _gather_forward("group_gather_forward", "group_gather_forward_kernel", sources, indices, targets, grouped=True)
+
+
+def _gather_backward(name, kernel, target_grads, indices, source_grads, num_sources, grouped):
+    _check_cuda_contiguous(target_grads, "target_grads")
+    _check_cuda_contiguous(indices, "indices")
+    _check_cuda_contiguous(source_grads, "source_grads")
+    _check_long(indices, "indices")
+    sfx = _floating_suffix(target_grads, kernel)
+    _same_dtype(name, target_grads, source_grads)
+    B, C = target_grads.size(0), target_grads.size(1)
+    N = int(num_sources)
+    if source_grads.size(2) != N:
+        raise RuntimeError(f"{name}: source_grads has {source_grads.size(2)} sources, num_sources={N}")
+    dev, stream = _where(target_grads)
+    L = target_grads.size(2) * (target_grads.size(3) if grouped else 1)
+    nbytes = _lib.lib().v3d_scatter_workspace_bytes(B, N, L)
+    ws = _workspace(nbytes, target_grads)
+    if grouped:
+        fn = getattr(_lib.lib(), "v3d_group_gather_bwd_" + sfx)
+        rc = fn(target_grads.data_ptr(), indices.data_ptr(), source_grads.data_ptr(), B, C, N, target_grads.size(2),
+                target_grads.size(3), ws.data_ptr(), ws.numel(), dev, stream)
+    else:
+        fn = getattr(_lib.lib(), "v3d_gather_bwd_" + sfx)
+        rc = fn(target_grads.data_ptr(), indices.data_ptr(), source_grads.data_ptr(), B, C, N, target_grads.size(2),
+                ws.data_ptr(), ws.numel(), dev, stream)
+    _lib.check(rc, name)
+
+
+def gather_backward(target_grads, indices, source_grads, num_sources):
+    _gather_backward("gather_backward", "gather_backward_kernel", target_grads, indices, source_grads, num_sources,
+                     grouped=False)
+
+
+def group_gather_backward(target_grads, indices, source_grads, num_sources):
+    _gather_backward("group_gather_backward", "group_gather_backward_kernel", target_grads, indices, source_grads,
+                     num_sources, grouped=True)
+
+
+def three_nn(q_points, s_points, tnn_distances, tnn_indices):
+    _check_cuda_contiguous(q_points, "q_points")
+    _check_cuda_contiguous(s_points, "s_points")
+    _check_cuda_contiguous(tnn_distances, "tnn_distances")
+    _check_cuda_contiguous(tnn_indices, "tnn_indices")
+    _check_long(tnn_indices, "tnn_indices")
+    sfx = _floating_suffix(q_points, "three_nn_kernel")
+    _same_dtype("three_nn", q_points, s_points, tnn_distances)
+    B, Q, S = q_points.size(0), q_points.size(1), s_points.size(1)
+    dev, stream = _where(q_points)
+    fn = getattr(_lib.lib(), "v3d_three_nn_" + sfx)
+    _lib.check(fn(q_points.data_ptr(), s_points.data_ptr(), tnn_distances.data_ptr(), tnn_indices.data_ptr(), B, Q, S,
+                  dev, stream), "three_nn")
+
+
+def three_interpolate_forward(sources, indices, weights, targets):
+    _check_cuda_contiguous(sources, "sources")
+    _check_cuda_contiguous(indices, "indices")
+    _check_cuda_contiguous(weights, "weights")
+    _check_cuda_contiguous(targets, "targets")
+    _check_long(indices, "indices")
+    sfx = _floating_suffix(sources, "three_interpolate_forward_kernel")
+    _same_dtype("three_interpolate_forward", sources, weights, targets)
+    B, C, S = sources.size(0), sources.size(1), sources.size(2)
+    Q = indices.size(1)
+    dev, stream = _where(sources)
+    fn = getattr(_lib.lib(), "v3d_three_interp_fwd_" + sfx)
+    _lib.check(fn(sources.data_ptr(), indices.data_ptr(), weights.data_ptr(), targets.data_ptr(), B, C, S, Q, dev,
+                  stream), "three_interpolate_forward")
+
+
+def three_interpolate_backward(target_grads, indices, weights, source_grads, num_sources):
+    _check_cuda_contiguous(target_grads, "target_grads")
+    _check_cuda_contiguous(indices, "indices")
+    _check_cuda_contiguous(weights, "weights")
+    _check_cuda_contiguous(source_grads, "source_grads")
+    _check_long(indices, "indices")
+    sfx = _floating_suffix(target_grads, "three_interpolate_backward_kernel")
+    _same_dtype("three_interpolate_backward", target_grads, weights, source_grads)
+    B, C, Q = target_grads.size(0), target_grads.size(1), target_grads.size(2)
+    S = int(num_sources)
+    if source_grads.size(2) != S:
+        raise RuntimeError(f"three_interpolate_backward: source_grads has {source_grads.size(2)} sources, "
+                           f"num_sources={S}")
+    dev, stream = _where(target_grads)
+    nbytes = _lib.lib().v3d_scatter_workspace_bytes(B, S, Q * 3)
+    ws = _workspace(nbytes, target_grads)
+    fn = getattr(_lib.lib(), "v3d_three_interp_bwd_" + sfx)
+    rc = fn(target_grads.data_ptr(), indices.data_ptr(), weights.data_ptr(), source_grads.data_ptr(), B, C, S, Q,
+            ws.data_ptr(), ws.numel(), dev, stream)
+    _lib.check(rc, "three_interpolate_backward")
+
+
+def knn_points(q_points, s_points, knn_distances, knn_indices, num_neighbors):
+    _check_cuda_contiguous(q_points, "q_points")
+    _check_cuda_contiguous(s_points, "s_points")
+    _check_cuda_contiguous(knn_distances, "knn_distances")
+    _check_cuda_contiguous(knn_indices, "knn_indices")
+    _check_long(knn_indices, "knn_indices")
+    sfx = _floating_suffix(q_points, "knn_points_kernel")
+    _same_dtype("knn_points", q_points, s_points, knn_distances)
+    B, M, N = q_points.size(0), q_points.size(1), s_points.size(1)
+    dev, stream = _where(q_points)
+    fn = getattr(_lib.lib(), "v3d_knn_points_" + sfx)
+    _lib.check(fn(q_points.data_ptr(), s_points.data_ptr(), knn_distances.data_ptr(), knn_indices.data_ptr(), B, M, N,
+                  int(num_neighbors), dev, stream), "knn_points")
+
+
+knn = knn_points  # ops/knn_points.py:36 calls ext_module.knn
+
+
+# --------------------------------------------------------------------------------------------------------
+# Entry points without a counterpart in the reference extension: the reference computes these with
+# torch.matmul + elementwise passes (ops/pairwise_distance.py) and with pykeops (ops/knn.py).
+# --------------------------------------------------------------------------------------------------------
+def pairwise_distance(x, y, out, normalized=False, squared=True, eps=1e-8, strict=False):
+    """x (batch,N,C), y (batch,M,C), out (batch,N,M); fp32, contiguous, in place."""
+    for t, name in ((x, "x"), (y, "y"), (out, "out")):
+        _check_cuda_contiguous(t, name)
+        _check_float(t, name)
+    batch, N, C = x.shape
+    M = y.shape[1]
+    flags = (1 if normalized else 0) | (0 if squared else 2) | (4 if strict else 0)
+    dev, stream = _where(x)
+    _lib.check(_lib.lib().v3d_pairwise_distance_f32(x.data_ptr(), y.data_ptr(), out.data_ptr(), batch, N, M, C, flags,
+                                                    float(eps), dev, stream), "pairwise_distance")
+
+
+def radius_count(q_points, s_points, counts, radius):
+    """q (B,M,3), s (B,N,3) fp32 -> counts (B,M) int64 of supports strictly closer than ``radius``."""
+    _check_cuda_contiguous(q_points, "q_points")
+    _check_cuda_contiguous(s_points, "s_points")
+    _check_cuda_contiguous(counts, "counts")
+    _check_float(q_points, "q_points")
+    _check_float(s_points, "s_points")
+    _check_long(counts, "counts")
+    B, M, N = q_points.size(0), q_points.size(1), s_points.size(1)
+    dev, stream = _where(q_points)
+    _lib.check(_lib.lib().v3d_radius_count_f32(q_points.data_ptr(), s_points.data_ptr(), counts.data_ptr(), B, M, N,
+                                               float(radius), dev, stream), "radius_count")
+
+
+def knn_feat(x, y, distances, indices, num_neighbors, index_offset=0):
+    """x (batch,N,C), y (batch,M,C) -> distances (batch,N,k) fp32 (Euclidean), indices (batch,N,k) int64."""
+    for t, name in ((x, "x"), (y, "y"), (distances, "distances")):
+        _check_cuda_contiguous(t, name)
+        _check_float(t, name)
+    _check_cuda_contiguous(indices, "indices")
+    _check_long(indices, "indices")
+    batch, N, C = x.shape
+    M = y.shape[1]
+    k = int(num_neighbors)
+    dev, stream = _where(x)
+    nbytes = _lib.lib().v3d_knn_feat_workspace_bytes(batch, N, max(M, 1), C, k)
+    ws = _workspace(nbytes, x)
+    rc = _lib.lib().v3d_knn_feat_f32(x.data_ptr(), y.data_ptr(), distances.data_ptr(), indices.data_ptr(), batch, N, M,
+                                     C, k, int(index_offset), ws.data_ptr(), ws.numel(), dev, stream)
+    _lib.check(rc, "knn_feat")
+
+
+def topk_merge(parts_distances, parts_indices, distances, indices):
+    """parts (G,rows,k) sorted partial lists -> (rows,k) global top-k by (distance, index)."""
+    _check_cuda_contiguous(parts_distances, "parts_distances")
+    _check_cuda_contiguous(parts_indices, "parts_indices")
+    _check_cuda_contiguous(distances, "distances")
+    _check_cuda_contiguous(indices, "indices")
+    _check_float(parts_distances, "parts_distances")
+    _check_float(distances, "distances")
+    _check_long(parts_indices, "parts_indices")
+    _check_long(indices, "indices")
+    G, rows, k = parts_distances.shape
+    dev, stream = _where(parts_distances)
+    _lib.check(_lib.lib().v3d_topk_merge_f32(parts_distances.data_ptr(), parts_indices.data_ptr(),
+                                             distances.data_ptr(), indices.data_ptr(), G, rows, k, dev, stream),
+               "topk_merge")

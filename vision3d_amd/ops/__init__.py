@@ -1,0 +1,24 @@
+"""Host-side mirror of the hot-path subset of the reference's ``vision3d.ops`` package.
+
+Same names, signatures, return values and error behaviour as the reference wrappers
+(``/root/reference/vision3d/ops/__init__.py`` and the per-op files cited in each module), re-backed by
+``vision3d_amd.ext`` (hand-written gfx950 kernels behind a C ABI).  ``vision3d_amd.install()`` registers this
+package as ``vision3d.ops`` / ``vision3d.ext`` so unchanged model code imports it.
+"""
+from .ball_query import ball_query
+from .conversion import batch_to_pack, batch_to_pack_with_lengths, pack_to_batch
+from .furthest_point_sample import furthest_point_sample
+from .gather import gather
+from .group_gather import group_gather
+from .knn import knn, knn_pack_mode
+from .knn_points import knn_points
+from .pairwise_distance import pairwise_distance
+from .radius_search import radius_count_pack_mode, radius_search_pack_mode
+from .three_interpolate import three_interpolate
+from .three_nn import three_nn
+
+__all__ = [
+    "ball_query", "batch_to_pack", "batch_to_pack_with_lengths", "pack_to_batch", "furthest_point_sample", "gather",
+    "group_gather", "knn", "knn_pack_mode", "knn_points", "pairwise_distance", "radius_count_pack_mode",
+    "radius_search_pack_mode", "three_interpolate", "three_nn",
+]

@@ -1,0 +1,32 @@
+"""Radius search in pack mode -- mirrors ``vision3d/ops/radius_search.py:44-107``.
+
+Same definition as the reference: the ``neighbor_limit`` nearest supports of each query inside its own cloud,
+those farther than ``radius`` replaced by the sentinel index N_total (= s_points.shape[0]).
+"""
+import torch
+
+from .. import ext
+from .conversion import batch_to_pack, pack_to_batch
+from .knn import keops_knn
+
+
+def radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, inf=1e10):
+    """q_points (M, 3), s_points (N, 3), lengths (B,) -> neighbor indices (M, neighbor_limit), N where absent."""
+    batch_q_points, batch_q_masks = pack_to_batch(q_points, q_lengths, fill_value=inf)  # (B, M', 3)
+    batch_s_points, _ = pack_to_batch(s_points, s_lengths, fill_value=inf)  # (B, N', 3)
+    batch_knn_distances, batch_knn_indices = keops_knn(batch_q_points, batch_s_points, neighbor_limit)
+    batch_start_index = torch.cumsum(s_lengths, dim=0) - s_lengths
+    batch_knn_indices = batch_knn_indices + batch_start_index.view(-1, 1, 1)
+    batch_knn_indices.masked_fill_(torch.gt(batch_knn_distances, radius), s_points.shape[0])
+    knn_indices, _ = batch_to_pack(batch_knn_indices, batch_q_masks)  # (M, K)
+    return knn_indices
+
+
+def radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf=1e10):
+    """Number of supports strictly inside ``radius`` of each query (reference: relu(radius - d).sign().sum())."""
+    batch_q_points, batch_q_masks = pack_to_batch(q_points, q_lengths, fill_value=inf)
+    batch_s_points, _ = pack_to_batch(s_points, s_lengths, fill_value=inf)
+    counts = torch.zeros(batch_q_points.shape[:2], dtype=torch.long, device=q_points.device)
+    ext.radius_count(batch_q_points.contiguous(), batch_s_points.contiguous(), counts, radius)
+    radius_counts, _ = batch_to_pack(counts, batch_q_masks)
+    return radius_counts
