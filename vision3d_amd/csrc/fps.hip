@@ -2,172 +2,247 @@
 // Semantics: furthest_point_sample_cuda.cuh:29-88 of the reference (start at point 0; each round updates the
 // running min squared distance of every point to the chosen set and picks the arg-max).
 //
-// gfx950 design: the M-1 rounds are a serial dependency chain, so the only lever is the latency of one round.
+// gfx950 design: the M-1 rounds are a serial dependency chain, so the only lever is the latency of one round
+// (a wave issues one instruction every ~4.5 cycles, so a round costs ~4.5 x its per-wave instruction count plus
+// the LDS / barrier round trips; measured with tools/fps_probe.cpp).
 //   * The cloud stays ON CHIP for the whole kernel: every thread keeps PPT points (x, y, z, running
-//     min-distance, tie priority) in VGPRs -- a CU has 512 KiB of them, 3x its LDS -- so a round touches no
-//     global memory (the reference re-reads 20 B/point/round through L2).
-//   * arg-max: one 64-bit key per point = (float bits of the distance) << 32 | ~priority; the per-thread scan,
-//     a DPP butterfly inside each 16-lane row, readlane across the four rows, then ONE LDS slot per wave
-//     carrying (key, x, y, z) of its winner and ONE barrier per round (slots double-buffered by round parity).
-//     The winner's coordinates travel with the key, so no thread ever looks a point up by index.
+//     min-distance) in VGPRs -- a CU has 512 KiB of them, 3x its LDS -- so a round touches no global memory
+//     (the reference re-reads 20 B/point/round through L2).  A float4 copy of the points sits in LDS only to
+//     look the round's winner up by index.
+//   * arg-max per round: per-thread strict-'>' scan (packed fp32 math), a six-step DPP max butterfly per wave
+//     (one VALU instruction per step), then the wave's winner lane publishes ONE 64-bit key
+//     (distance bits << 32 | ~priority) with an LDS atomic max; after ONE barrier every thread reads the winning
+//     key back, decodes the point index and fetches its coordinates from the LDS table.  No second reduction
+//     stage, no broadcast step; the key cell is triple-buffered so it can be reset without a second barrier.
 //   * Ties: the reference's winner among equally-far points depends on ITS launch geometry (block =
 //     opt_n_threads(N), per-thread strided first-max, then a shared-memory tree that prefers the lower slot):
-//     the winner is the point with the smallest (bit-reversed (p mod block), p div block).  That pair is the
-//     `priority` above, so our result equals the reference's whatever OUR block size is.
-//   * Clouds larger than the register budget fall back to a streaming variant (points from L2, distances in
-//     the caller's scratch buffer), same reduction.
+//     the winner is the point with the smallest (bit-reversed (p mod block), p div block).  That pair, packed as
+//     (bitrev << 22 | p div block), is the `priority`: inside a thread it grows with the scan order (our block
+//     size is a multiple of the reference's), across lanes it is only consulted on exact ties, and across waves
+//     it rides in the low word of the atomic key -- so our result equals the reference's whatever OUR geometry.
+//   * Clouds beyond the register / LDS budget (N > 8192) take the slot variant (winner coordinates travel
+//     through a per-wave LDS slot) or, past 16384 points, the streaming variant (points from L2, distances in
+//     the caller's scratch buffer); same reduction, same tie rule.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
 namespace v3d {
 
-__device__ __forceinline__ uint32_t fps_priority(int p, int lb, int qs) {
-  uint32_t low = (uint32_t)p & ((1u << lb) - 1u);
-  uint32_t br = lb ? (__brev(low) >> (32 - lb)) : 0u;
-  return br * (uint32_t)qs + ((uint32_t)p >> lb);
+constexpr int kPrioShift = 22;  // priority = bitrev(p mod block) << 22 | (p div block); p div block < 2^22
+
+// One DPP max step as a single VALU instruction (hipcc expands fmaxf(v, dpp(v)) into five: a zeroing move, the DPP
+// move, a NaN-canonicalising max and the max).  `s_nop 1` covers the two wait states a DPP read needs after the
+// VALU write of the same register.  Lanes a row_mask leaves out keep their value (the destination is the source).
+#define V3D_DPP_MAX(v, CTRL_TEXT) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL_TEXT : "+v"(v))
+#define V3D_DPP_UMIN(v, CTRL_TEXT) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 " CTRL_TEXT : "+v"(v))
+
+// max over the 64 lanes, returned wave-uniform.  Inputs are >= 0 and never NaN.
+__device__ __forceinline__ float wave_max_f32(float v) {
+  V3D_DPP_MAX(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_MAX(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_MAX(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+  V3D_DPP_MAX(v, "row_mirror row_mask:0xf bank_mask:0xf");
+  V3D_DPP_MAX(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");  // rows 1,3 <- max with last lane of rows 0,2
+  V3D_DPP_MAX(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");  // rows 2,3 <- max with lane 31
+  asm volatile("s_nop 1" ::: "memory");
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ int fps_point_of_priority(uint32_t prio, int lb, int qs) {
-  uint32_t br = prio / (uint32_t)qs, stride_i = prio % (uint32_t)qs;
-  uint32_t low = lb ? (__brev(br) >> (32 - lb)) : 0u;
-  return (int)((stride_i << lb) + low);
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  V3D_DPP_UMIN(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_UMIN(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_UMIN(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+  V3D_DPP_UMIN(v, "row_mirror row_mask:0xf bank_mask:0xf");
+  V3D_DPP_UMIN(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  V3D_DPP_UMIN(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  asm volatile("s_nop 1" ::: "memory");
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
-  int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
-  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) {
-  return a > b ? a : b;
-}
-// max over the 16 lanes of each DPP row, result in every lane of the row
-__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {
-  v = umax64(v, dpp_u64<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = umax64(v, dpp_u64<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = umax64(v, dpp_u64<0x141>(v));  // row_half_mirror
-  v = umax64(v, dpp_u64<0x140>(v));  // row_mirror
-  return v;
-}
-__device__ __forceinline__ unsigned long long read_lane_u64(unsigned long long v, int lane) {
-  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
-  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
-  return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  v = row_max_u64(v);
-  unsigned long long a = read_lane_u64(v, 0), b = read_lane_u64(v, 16), c = read_lane_u64(v, 32),
-                     d = read_lane_u64(v, 48);
-  return umax64(umax64(a, b), umax64(c, d));
+// Diagnostic build only (tools/fps_probe.cpp defines V3D_FPS_STAMPS): per-segment cycle shares of one wave.
+#ifdef V3D_FPS_STAMPS
+__device__ unsigned long long g_fps_stamps[16];
+#define V3D_STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define V3D_STAMP(k)                                          \
+  do {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                       \
+    st_acc[k] += st_now - st_prev;                            \
+    st_prev = st_now;                                         \
+    __builtin_amdgcn_sched_barrier(0);                        \
+  } while (0)
+#define V3D_STAMP_FLUSH                    \
+  if (blockIdx.x == 0 && threadIdx.x == 0) \
+    for (int k_ = 0; k_ < 8; ++k_) g_fps_stamps[k_] = st_acc[k_]
+#else
+#define V3D_STAMP_DECL
+#define V3D_STAMP(k)
+#define V3D_STAMP_FLUSH
+#endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// min of two non-NaN floats as ONE v_min_f32 (fminf costs an extra NaN-canonicalising v_max per operand)
+__device__ __forceinline__ float fps_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
-struct alignas(16) FpsSlot {
-  unsigned long long key;
-  float x, y, z, pad;
-};
+enum FpsMode { kFpsTable = 0, kFpsSlots = 1, kFpsStream = 2 };
 
-// RESIDENT: points + distances in VGPRs (PPT per thread).  Otherwise streamed from global every round.
-template <int THREADS, int PPT, bool RESIDENT>
+// kFpsTable : points + distances in VGPRs, winner coordinates from an LDS float4 table (N*16 B of dynamic LDS)
+// kFpsSlots : points + distances in VGPRs, winner coordinates through a per-wave LDS slot
+// kFpsStream: points streamed from L2 every round, distances in the caller's buffer, per-wave slots
+// THREADS is a multiple of the reference block size, so all points of one thread share (p mod block): their tie
+// priority grows with the scan order and the strict '>' of the scan already picks the reference's winner.
+template <int THREADS, int PPT, int MODE>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float* __restrict__ pts, float* __restrict__ dist_io,
-                                                      int64_t* __restrict__ out_idx, int N, int M, int lb, int qs) {
+                                                      int64_t* __restrict__ out_idx, int N, int M, int lb) {
   constexpr int W = THREADS / 64;
-  __shared__ FpsSlot slots[2][W];
-  if (M <= 0) return;  // furthest_point_sample_cuda.cuh:37
+  constexpr bool RESIDENT = MODE != kFpsStream;
+  extern __shared__ float4 table[];               // kFpsTable only
+  __shared__ unsigned long long cell[3];          // winning key of round s lives in cell[s % 3]
+  __shared__ float4 slots[2][W];                  // kFpsSlots / kFpsStream: winner coordinates of each wave
+  if (M <= 0) return;                             // furthest_point_sample_cuda.cuh:37
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   pts += (int64_t)b * N * 3;
   dist_io += (int64_t)b * N;
   out_idx += (int64_t)b * M;
 
+  // priority of this thread's i-th point: prio_base + i * prio_step (see the header comment)
+  const uint32_t low = (uint32_t)tid & ((1u << lb) - 1u);
+  const uint32_t prio_base = ((lb ? (__brev(low) >> (32 - lb)) : 0u) << kPrioShift) | ((uint32_t)tid >> lb);
+  const uint32_t prio_step = (uint32_t)THREADS >> lb;
+
   float px[PPT], py[PPT], pz[PPT], pd[PPT];
-  uint32_t np[PPT];  // ~priority; 0 for padding lanes so they lose every comparison
   if (RESIDENT) {
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      int p = i * THREADS + tid;
-      bool ok = p < N;
-      int pp = ok ? p : 0;
+      const int p = i * THREADS + tid;
+      const bool ok = p < N;
+      const int pp = ok ? p : 0;
       px[i] = pts[pp * 3 + 0];
       py[i] = pts[pp * 3 + 1];
       pz[i] = pts[pp * 3 + 2];
-      pd[i] = ok ? dist_io[pp] : 0.0f;
-      np[i] = ok ? ~fps_priority(p, lb, qs) : 0u;
+      pd[i] = ok ? dist_io[pp] : -1.0f;  // padding: min(d, -1) = -1 never beats a real point (d >= 0)
+      if (MODE == kFpsTable && ok) table[p] = make_float4(px[i], py[i], pz[i], 0.f);
     }
   }
-
+  if (tid < 3) cell[tid] = 0ull;
   float x1 = pts[0], y1 = pts[1], z1 = pts[2];  // old = 0  (:50,:57-59)
   if (tid == 0) out_idx[0] = 0;                 // :51
+  __syncthreads();
 
+  V3D_STAMP_DECL;
   for (int s = 1; s < M; ++s) {
-    unsigned long long best = 0ull;
-    float bx = 0.f, by = 0.f, bz = 0.f;
+    V3D_STAMP(0);
+    float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;  // best = -1 (:56)
+    int bi = 0;
     if (RESIDENT) {
+      // two points per packed fp32 instruction (v_pk_add/v_pk_mul: same IEEE results as the scalar forms)
 #pragma unroll
-      for (int i = 0; i < PPT; ++i) {
-        float dx = x1 - px[i], dy = y1 - py[i], dz = z1 - pz[i];
-        float d = (dx * dx + dy * dy) + dz * dz;  // :64, reference order, no contraction
-        d = fminf(d, pd[i]);                      // :65
-        pd[i] = d;                                // :66 (kept in registers; written back once at the end)
-        unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | np[i];
-        bool gt = key > best;
-        best = gt ? key : best;
-        bx = gt ? px[i] : bx;
-        by = gt ? py[i] : by;
-        bz = gt ? pz[i] : bz;
+      for (int i = 0; i < PPT; i += 2) {
+        constexpr bool PAIR = (PPT % 2 == 0);
+        if (PAIR) {
+          const f32x2 dx = f32x2{x1, x1} - f32x2{px[i], px[i + 1]};
+          const f32x2 dy = f32x2{y1, y1} - f32x2{py[i], py[i + 1]};
+          const f32x2 dz = f32x2{z1, z1} - f32x2{pz[i], pz[i + 1]};
+          const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;  // :64, reference order, no contraction
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float d = fps_min(d2[e], pd[i + e]);  // :65
+            pd[i + e] = d;                              // :66 (kept in registers; written back once at the end)
+            const bool gt = d > bd;                     // :67 strict: the first maximum in scan order wins
+            bd = gt ? d : bd;
+            bi = gt ? i + e : bi;
+            if (MODE == kFpsSlots) {
+              bx = gt ? px[i + e] : bx;
+              by = gt ? py[i + e] : by;
+              bz = gt ? pz[i + e] : bz;
+            }
+          }
+        } else {  // PPT == 1
+          const float dx = x1 - px[i], dy = y1 - py[i], dz = z1 - pz[i];
+          float d = (dx * dx + dy * dy) + dz * dz;
+          d = fps_min(d, pd[i]);
+          pd[i] = d;
+          const bool gt = d > bd;
+          bd = gt ? d : bd;
+          bi = gt ? i : bi;
+          if (MODE == kFpsSlots) {
+            bx = gt ? px[i] : bx;
+            by = gt ? py[i] : by;
+            bz = gt ? pz[i] : bz;
+          }
+        }
       }
     } else {
-      for (int p = tid; p < N; p += THREADS) {
-        float x2 = pts[p * 3 + 0], y2 = pts[p * 3 + 1], z2 = pts[p * 3 + 2];
-        float dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;
+      int i = 0;
+      for (int p = tid; p < N; p += THREADS, ++i) {
+        const float x2 = pts[p * 3 + 0], y2 = pts[p * 3 + 1], z2 = pts[p * 3 + 2];
+        const float dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;
         float d = (dx * dx + dy * dy) + dz * dz;
         d = fminf(d, dist_io[p]);
         dist_io[p] = d;
-        unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (~fps_priority(p, lb, qs));
-        bool gt = key > best;
-        best = gt ? key : best;
+        const bool gt = d > bd;
+        bd = gt ? d : bd;
+        bi = gt ? i : bi;
         bx = gt ? x2 : bx;
         by = gt ? y2 : by;
         bz = gt ? z2 : bz;
       }
     }
-    // wave arg-max; keys of real points are unique, so exactly one lane matches (several only if the whole
-    // wave holds padding, key 0 -- then any of them may publish the losing slot)
-    const unsigned long long wmax = wave_max_u64(best);
-    const unsigned long long match = __ballot(best == wmax);
-    FpsSlot* round_slots = slots[s & 1];
-    if (lane == __builtin_ffsll((long long)match) - 1) {
-      FpsSlot v;
-      v.key = wmax;
-      v.x = bx;
-      v.y = by;
-      v.z = bz;
-      v.pad = 0.f;
-      round_slots[wave] = v;
+    V3D_STAMP(1);
+    // wave arg-max.  Padding-only lanes carry -1 (clamped to 0 for the butterfly) and never equal the maximum.
+    const float wmax = wave_max_f32(fmaxf(bd, 0.0f));
+    const unsigned long long match = __ballot(bd == wmax);
+    const uint32_t prio = prio_base + (uint32_t)bi * prio_step;
+    V3D_STAMP(2);
+    if (match != 0ull) {  // (a wave that holds padding only publishes nothing)
+      int wl = __builtin_ffsll((long long)match) - 1;
+      if (__builtin_popcountll(match) > 1) {  // exact tie inside the wave: lowest priority value wins
+        const bool in = (match >> lane) & 1ull;
+        const uint32_t mine = in ? prio : 0xffffffffu;
+        const uint32_t best = wave_min_u32(mine);
+        wl = __builtin_ffsll((long long)__ballot(in && mine == best)) - 1;
+      }
+      if (lane == wl) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(~prio);
+#ifdef V3D_FPS_EXPERIMENT_STORE
+        cell[s % 3] = key;
+#else
+        atomicMax(&cell[s % 3], key);  // ds_max_u64: equal distances in different waves resolve by priority here
+#endif
+        if (MODE != kFpsTable) slots[s & 1][wave] = make_float4(bx, by, bz, 0.f);
+      }
     }
+    if (tid == 0) cell[(s + 1) % 3] = 0ull;  // last read two rounds ago, next written after this round's barrier
+    V3D_STAMP(3);
     __syncthreads();
-    // every wave reduces the W published slots on its own (no second barrier, no broadcast step)
-    unsigned long long k2 = lane < W ? round_slots[lane].key : 0ull;
-    unsigned long long gmax;
-    if (W > 1) {
-      unsigned long long r = row_max_u64(k2);  // W <= 16: one DPP row
-      gmax = read_lane_u64(r, 0);
-    } else {
-      gmax = read_lane_u64(k2, 0);
-    }
-    const unsigned long long m2 = __ballot(lane < W && k2 == gmax);
-    const int wwin = __builtin_ffsll((long long)m2) - 1;
-    const FpsSlot win = round_slots[wwin];
-    x1 = win.x;
-    y1 = win.y;
-    z1 = win.z;
-    if (tid == 0) out_idx[s] = (int64_t)fps_point_of_priority(~(uint32_t)gmax, lb, qs);  // :85-86
+    V3D_STAMP(4);
+    const unsigned long long key = cell[s % 3];
+    const uint32_t wprio = ~(uint32_t)key;
+    const uint32_t wq = wprio & ((1u << kPrioShift) - 1u), wbr = wprio >> kPrioShift;
+    const int wp = (int)((wq << lb) + (lb ? (__brev(wbr) >> (32 - lb)) : 0u));  // the round's winner (:85)
+    V3D_STAMP(5);
+    float4 w4;
+    if (MODE == kFpsTable) w4 = table[wp];
+    else w4 = slots[s & 1][(wp & (THREADS - 1)) >> 6];  // the wave that owns point wp
+    x1 = w4.x;
+    y1 = w4.y;
+    z1 = w4.z;
+    if (tid == 0) out_idx[s] = (int64_t)wp;  // :86
+    V3D_STAMP(6);
   }
+  V3D_STAMP_FLUSH;
 
   if (RESIDENT) {  // leave the scratch buffer as the reference does: final running min-distances
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      int p = i * THREADS + tid;
+      const int p = i * THREADS + tid;
       if (p < N) dist_io[p] = pd[i];
     }
   }
@@ -210,18 +285,33 @@ int v3d_fps_f32(const float* points, float* distances, int64_t* indices, int B, 
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int bs = v3d_fps_ref_block(N);
   const int lb = ilog2_floor(bs);
-  const int qs = (int)ceil_div(N, bs);
-#define V3D_FPS(T_, P_, R_)                                                                                \
-  hipLaunchKernelGGL((fps_kernel<T_, P_, R_>), dim3(B), dim3(T_), 0, stream, points, distances, indices, N, M, \
-                     lb, qs)
-  if (N <= 64) V3D_FPS(64, 1, true);
-  else if (N <= 256) V3D_FPS(64, 4, true);
-  else if (N <= 1024) V3D_FPS(256, 4, true);
-  else if (N <= 2048) V3D_FPS(512, 4, true);
-  else if (N <= 4096) V3D_FPS(1024, 4, true);
-  else if (N <= 8192) V3D_FPS(1024, 8, true);
-  else if (N <= 16384) V3D_FPS(1024, 16, true);
-  else V3D_FPS(1024, 1, false);
+  const size_t table_bytes = (size_t)N * sizeof(float4);
+#define V3D_FPS(T_, P_, M_)                                                                               \
+  hipLaunchKernelGGL((fps_kernel<T_, P_, M_>), dim3(B), dim3(T_), (M_) == kFpsTable ? table_bytes : 0, stream, \
+                     points, distances, indices, N, M, lb)
+  // THREADS must be a multiple of the reference block `bs` (see the kernel comment): bs <= 512 is a power of two
+  if (N <= 64) V3D_FPS(64, 1, kFpsTable);          // bs <= 64
+  else if (N < 128) V3D_FPS(64, 2, kFpsTable);     // bs == 64
+  else if (N < 256) V3D_FPS(128, 2, kFpsTable);    // bs == 128
+  else if (N < 512) V3D_FPS(256, 2, kFpsTable);    // bs == 256
+  else if (N <= 1024) V3D_FPS(512, 2, kFpsTable);  // bs == 512 from here on
+  else if (N <= 2048) V3D_FPS(512, 4, kFpsTable);
+  else if (N <= 4096) {
+    static const int variant = getenv("V3D_FPS_VARIANT") ? atoi(getenv("V3D_FPS_VARIANT")) : 0;  // tuning aid
+    if (variant == 1) V3D_FPS(1024, 4, kFpsTable);
+    else if (variant == 2) V3D_FPS(512, 8, kFpsSlots);
+    else V3D_FPS(512, 8, kFpsTable);
+  } else if (N <= 8192) {
+    static bool attr_set[64] = {};  // 128 KiB of dynamic LDS needs the opt-in, once per device
+    if (device < 0 || device >= 64 || !attr_set[device]) {
+      V3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<1024, 8, kFpsTable>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(float4)),
+                  what);
+      if (device >= 0 && device < 64) attr_set[device] = true;
+    }
+    V3D_FPS(1024, 8, kFpsTable);
+  } else if (N <= 16384) V3D_FPS(1024, 16, kFpsSlots);
+  else V3D_FPS(1024, 1, kFpsStream);
 #undef V3D_FPS
   return launch_status(what);
 }

@@ -35,18 +35,21 @@ __device__ __forceinline__ int fetch_index(const int64_t* __restrict__ idx, int6
   return (v >= 0 && v < N) ? v : -1;
 }
 
-template <typename E, int VEC, int R, bool VEC_STORE>
+// LDS path.  NSTAGE = 16-byte vectors each thread moves per source row (0: rows that are not 16-byte
+// tileable are staged element-wise).  Row buffers hold N+1 elements: slot N is a zero that out-of-range
+// indices are redirected to, so the gather loop carries no per-element range check.  Requires 16-byte stores
+// (L % VEC == 0, aligned output); everything else takes the direct kernel.
+template <typename E, int VEC, int R, int NSTAGE>
 __global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
     const E* __restrict__ src, const int64_t* __restrict__ idx, E* __restrict__ out, int C, int N, int64_t L,
-    int CT, int row_vec_ok) {
+    int CT, int buf_elems) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  E* smem = reinterpret_cast<E*>(smem_raw);
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * CT;
   const int c1 = min(c0 + CT, C);
   const int64_t tile0 = (int64_t)blockIdx.x * (kGatherThreads * VEC * R);
-  const size_t row_bytes = ((size_t)N * sizeof(E) + 15) & ~(size_t)15;
-  E* buf[2] = {reinterpret_cast<E*>(smem_raw), reinterpret_cast<E*>(smem_raw + row_bytes)};
 
   int my[R][VEC];
   const int64_t* bidx = idx + (int64_t)b * L;
@@ -54,67 +57,67 @@ __global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
   for (int r = 0; r < R; ++r) {
     int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) my[r][e] = fetch_index(bidx, p0 + e, L, N);
+    for (int e = 0; e < VEC; ++e) {
+      int v = fetch_index(bidx, p0 + e, L, N);
+      my[r][e] = v < 0 ? N : v;
+    }
+  }
+  if (tid == 0) {
+    smem[N] = E(0);
+    smem[buf_elems + N] = E(0);
   }
 
-  constexpr int kRowVec = 16 / sizeof(E);  // elements per 16-byte staging vector
-  constexpr int kMaxStage = 8;             // host guarantees N*sizeof(E) <= 8*256*16 = 32 KiB
   const int nvec = (int)(((size_t)N * sizeof(E)) / 16);
-
-  auto stage_row_sync = [&](int c, E* dst) {  // first row: plain load + store
-    const E* row = src + ((int64_t)b * C + c) * N;
-    if (row_vec_ok) {
+  uint4 stg[NSTAGE > 0 ? NSTAGE : 1];
+  // first row: straight into buffer 0
+  {
+    const E* row = src + ((int64_t)b * C + c0) * N;
+    if (NSTAGE > 0) {
       const uint4* row4 = reinterpret_cast<const uint4*>(row);
-      uint4* dst4 = reinterpret_cast<uint4*>(dst);
-      for (int i = tid; i < nvec; i += kGatherThreads) dst4[i] = row4[i];
-      for (int i = nvec * kRowVec + tid; i < N; i += kGatherThreads) dst[i] = row[i];
+      uint4* dst4 = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+      for (int i = 0; i < NSTAGE; ++i) {
+        int v = i * kGatherThreads + tid;
+        if (v < nvec) dst4[v] = row4[v];
+      }
     } else {
-      for (int i = tid; i < N; i += kGatherThreads) dst[i] = row[i];
+      for (int i = tid; i < N; i += kGatherThreads) smem[i] = row[i];
     }
-  };
-
-  stage_row_sync(c0, buf[0]);
+  }
   for (int c = c0; c < c1; ++c) {
     __syncthreads();
-    const E* cur = buf[(c - c0) & 1];
-    E* nxt = buf[(c - c0 + 1) & 1];
+    const int which = (c - c0) & 1;
+    const E* cur = smem + which * buf_elems;
+    E* nxt = smem + (which ^ 1) * buf_elems;
     const bool have_next = (c + 1 < c1);
-    // issue the next row's global loads before the gathers so their latency hides under the stores
-    uint4 stg[kMaxStage];
-    const E* nrow = src + ((int64_t)b * C + (c + 1)) * N;
-    if (have_next && row_vec_ok) {
+    const E* nrow = src + ((int64_t)b * C + (have_next ? c + 1 : c)) * N;
+    if (NSTAGE > 0) {  // next row's loads are in flight while this row is gathered and stored
       const uint4* row4 = reinterpret_cast<const uint4*>(nrow);
 #pragma unroll
-      for (int i = 0; i < kMaxStage; ++i) {
+      for (int i = 0; i < NSTAGE; ++i) {
         int v = i * kGatherThreads + tid;
-        if (v < nvec) stg[i] = row4[v];
+        stg[i] = (have_next && v < nvec) ? row4[v] : make_uint4(0, 0, 0, 0);
       }
     }
     E* orow = out + ((int64_t)b * C + c) * L;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
-      if (p0 >= L) continue;
-      Pack<E, VEC> pk;
+      if (p0 < L) {
+        Pack<E, VEC> pk;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) pk.v[e] = my[r][e] >= 0 ? cur[my[r][e]] : E(0);
-      if (VEC_STORE) {
+        for (int e = 0; e < VEC; ++e) pk.v[e] = cur[my[r][e]];
         *reinterpret_cast<Pack<E, VEC>*>(orow + p0) = pk;
-      } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (p0 + e < L) orow[p0 + e] = pk.v[e];
       }
     }
     if (have_next) {
-      if (row_vec_ok) {
+      if (NSTAGE > 0) {
         uint4* dst4 = reinterpret_cast<uint4*>(nxt);
 #pragma unroll
-        for (int i = 0; i < kMaxStage; ++i) {
+        for (int i = 0; i < NSTAGE; ++i) {
           int v = i * kGatherThreads + tid;
           if (v < nvec) dst4[v] = stg[i];
         }
-        for (int i = nvec * kRowVec + tid; i < N; i += kGatherThreads) nxt[i] = nrow[i];
       } else {
         for (int i = tid; i < N; i += kGatherThreads) nxt[i] = nrow[i];
       }
@@ -178,8 +181,9 @@ static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, i
   const E* src = static_cast<const E*>(src_);
   E* out = static_cast<E*>(out_);
   const bool vec_store = (L % VEC == 0) && ((uintptr_t)out % (sizeof(E) * VEC) == 0);
-  const size_t row_bytes = align_up((size_t)N * sizeof(E), 16);
-  const int row_vec_ok = ((size_t)N * sizeof(E) % 16 == 0) && ((uintptr_t)src % 16 == 0);
+  const size_t row_bytes = (size_t)N * sizeof(E);
+  const bool row_vec_ok = (row_bytes % 16 == 0) && ((uintptr_t)src % 16 == 0);
+  const int buf_elems = (int)(align_up(row_bytes + sizeof(E), 16) / sizeof(E));  // N + zero slot, 16-B multiple
   // positions per workgroup: R vectors of VEC per thread
   constexpr int R_BIG = 8, R_SMALL = 2;
   const bool big = L >= (int64_t)kGatherThreads * VEC * R_BIG;
@@ -189,27 +193,39 @@ static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, i
   int CT = 16;
   while (CT > 2 && xblocks * ceil_div(C, CT) * B < 2048) CT >>= 1;
   if (CT > C) CT = C;
-  int mode = gather_mode_override();
-  bool use_lds = row_bytes <= 32768 && (int64_t)N * 2 <= (int64_t)kGatherThreads * VEC * R * CT;
-  if (mode == 1) use_lds = row_bytes <= 32768;
+  const int mode = gather_mode_override();
+  const bool lds_fits = row_bytes <= 32768;
+  bool use_lds = vec_store && lds_fits && (int64_t)N * 2 <= (int64_t)kGatherThreads * VEC * R * CT;
+  if (mode == 1) use_lds = vec_store && lds_fits;
   if (mode == 2) use_lds = false;
   dim3 grid((unsigned)xblocks, (unsigned)ceil_div(C, CT), (unsigned)B);
   dim3 block(kGatherThreads);
-#define V3D_LAUNCH_GF(RR, VS)                                                                              \
-  do {                                                                                                     \
-    if (use_lds)                                                                                           \
-      hipLaunchKernelGGL((gather_fwd_lds_kernel<E, VEC, RR, VS>), grid, block, 2 * row_bytes, stream, src, \
-                         idx, out, C, N, L, CT, row_vec_ok);                                               \
-    else                                                                                                   \
-      hipLaunchKernelGGL((gather_fwd_direct_kernel<E, VEC, RR, VS>), grid, block, 0, stream, src, idx,     \
-                         out, C, N, L, CT);                                                                \
+  if (use_lds) {
+    const size_t lds = 2 * (size_t)buf_elems * sizeof(E);
+    const int nvec_per_thread = row_vec_ok ? (int)ceil_div((int64_t)(row_bytes / 16), kGatherThreads) : 0;
+#define V3D_LAUNCH_LDS(RR, NS)                                                                               \
+  hipLaunchKernelGGL((gather_fwd_lds_kernel<E, VEC, RR, NS>), grid, block, lds, stream, src, idx, out, C, N, L, \
+                     CT, buf_elems)
+#define V3D_LAUNCH_LDS_R(RR)                         \
+  do {                                               \
+    if (nvec_per_thread == 0) V3D_LAUNCH_LDS(RR, 0); \
+    else if (nvec_per_thread <= 1) V3D_LAUNCH_LDS(RR, 1); \
+    else if (nvec_per_thread <= 4) V3D_LAUNCH_LDS(RR, 4); \
+    else V3D_LAUNCH_LDS(RR, 8);                      \
   } while (0)
-  if (big) {
-    if (vec_store) V3D_LAUNCH_GF(R_BIG, true); else V3D_LAUNCH_GF(R_BIG, false);
+    if (big) V3D_LAUNCH_LDS_R(R_BIG); else V3D_LAUNCH_LDS_R(R_SMALL);
+#undef V3D_LAUNCH_LDS_R
+#undef V3D_LAUNCH_LDS
   } else {
-    if (vec_store) V3D_LAUNCH_GF(R_SMALL, true); else V3D_LAUNCH_GF(R_SMALL, false);
+#define V3D_LAUNCH_DIRECT(RR, VS) \
+  hipLaunchKernelGGL((gather_fwd_direct_kernel<E, VEC, RR, VS>), grid, block, 0, stream, src, idx, out, C, N, L, CT)
+    if (big) {
+      if (vec_store) V3D_LAUNCH_DIRECT(R_BIG, true); else V3D_LAUNCH_DIRECT(R_BIG, false);
+    } else {
+      if (vec_store) V3D_LAUNCH_DIRECT(R_SMALL, true); else V3D_LAUNCH_DIRECT(R_SMALL, false);
+    }
+#undef V3D_LAUNCH_DIRECT
   }
-#undef V3D_LAUNCH_GF
   return launch_status("gather_forward");
 }
 
@@ -383,6 +399,85 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const T* __restrict__ 
     if (c0 + i < C) gsrc[((int64_t)b * C + c0 + i) * N + n] = acc[i];
 }
 
+// LDS variant of the ordered segment sum: one workgroup owns CT channels of one cloud and sweeps the target
+// positions in chunks of P; the chunk of grad_out (CT x P) is staged in LDS with coalesced 16-byte loads, then
+// every thread walks the (ascending) target lists of its NPT sources as far as the chunk reaches, adding from LDS.
+// grad_out is read from HBM exactly once; the CSR lists are re-read per channel tile from L2.  Summation order per
+// (b,c,n) is still ascending t, so the result is bit-identical to segment_sum_kernel and to the CPU oracle.
+template <typename T, int MODE, int CT, int NPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void segment_sum_lds_kernel(const T* __restrict__ gout, const T* __restrict__ w,
+                                                                  const int32_t* __restrict__ offsets,
+                                                                  const int32_t* __restrict__ sorted,
+                                                                  T* __restrict__ gsrc, int C, int N, int64_t L,
+                                                                  int64_t Lrow, int P, int vec_ok) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);  // [CT][P]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CT;
+  const int32_t* off = offsets + (int64_t)b * (N + 1);
+  const int32_t* srt = sorted + (int64_t)b * L;
+  const T* wb = MODE == 1 ? w + (int64_t)b * L : nullptr;
+  int cur[NPT], end[NPT];
+  T acc[NPT][CT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int n = j * THREADS + tid;
+    cur[j] = n < N ? off[n] : 0;
+    end[j] = n < N ? off[n + 1] : 0;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[j][i] = T(0);
+  }
+  constexpr int kVec = 16 / sizeof(T);
+  for (int64_t col0 = 0; col0 < Lrow; col0 += P) {
+    const int pc = (int)min((int64_t)P, Lrow - col0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      if (c0 + i < C) {
+        const T* row = gout + ((int64_t)b * C + c0 + i) * Lrow + col0;
+        T* dst = tile + i * P;
+        if (vec_ok) {
+          const int nv = pc / kVec;
+          for (int v = tid; v < nv; v += THREADS)
+            reinterpret_cast<uint4*>(dst)[v] = reinterpret_cast<const uint4*>(row)[v];
+          for (int e = nv * kVec + tid; e < pc; e += THREADS) dst[e] = row[e];
+        } else {
+          for (int e = tid; e < pc; e += THREADS) dst[e] = row[e];
+        }
+      }
+    }
+    __syncthreads();
+    const int64_t col_end = col0 + pc;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      while (cur[j] < end[j]) {
+        const int t = srt[cur[j]];
+        const int64_t col = MODE == 1 ? (int64_t)(t / 3) : (int64_t)t;
+        if (col >= col_end) break;
+        const T wt = MODE == 1 ? wb[t] : T(1);
+        const int lc = (int)(col - col0);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          T v = tile[i * P + lc];
+          if (MODE == 1) v = v * wt;
+          acc[j][i] = acc[j][i] + v;
+        }
+        ++cur[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int n = j * THREADS + tid;
+    if (n < N) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+        if (c0 + i < C) gsrc[((int64_t)b * C + c0 + i) * N + n] = acc[j][i];
+    }
+  }
+}
+
 template <typename T, int MODE>
 static int scatter_backward(const char* what, const T* gout, const int64_t* idx, const T* w, T* gsrc, int B, int C,
                             int N, int64_t L, void* workspace, size_t workspace_bytes, int device, void* stream_) {
@@ -426,11 +521,25 @@ static int scatter_backward(const char* what, const T* gout, const int64_t* idx,
                        ws.unsorted, N, L);
     hipLaunchKernelGGL(csr_rank_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.unsorted,
                        ws.sorted, N, L);
-    constexpr int CT = 8;
     const int64_t Lrow = MODE == 1 ? L / 3 : L;
-    dim3 grid((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, CT), (unsigned)B);
-    hipLaunchKernelGGL((segment_sum_kernel<T, MODE, CT>), grid, dim3(256), 0, stream, gout, w, ws.offsets,
-                       ws.sorted, gsrc, C, N, L, Lrow);
+    if (N <= 4096) {
+      constexpr int CT = 4, THREADS = 1024;
+      const int P = (int)std::min<int64_t>(16384 / sizeof(T), align_up((size_t)Lrow, 4));  // CT*P*sizeof(T) <= 64 KiB
+      const int vec_ok = (Lrow % (16 / sizeof(T)) == 0) && ((uintptr_t)gout % 16 == 0);
+      const size_t lds = (size_t)CT * P * sizeof(T);
+      dim3 grid((unsigned)ceil_div(C, CT), (unsigned)B);
+      if (N <= 1024)
+        hipLaunchKernelGGL((segment_sum_lds_kernel<T, MODE, CT, 1, THREADS>), grid, dim3(THREADS), lds, stream, gout,
+                           w, ws.offsets, ws.sorted, gsrc, C, N, L, Lrow, P, vec_ok);
+      else
+        hipLaunchKernelGGL((segment_sum_lds_kernel<T, MODE, CT, 4, THREADS>), grid, dim3(THREADS), lds, stream, gout,
+                           w, ws.offsets, ws.sorted, gsrc, C, N, L, Lrow, P, vec_ok);
+    } else {
+      constexpr int CT = 8;
+      dim3 grid((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, CT), (unsigned)B);
+      hipLaunchKernelGGL((segment_sum_kernel<T, MODE, CT>), grid, dim3(256), 0, stream, gout, w, ws.offsets,
+                         ws.sorted, gsrc, C, N, L, Lrow);
+    }
     rc = launch_status(what);
   } while (0);
   if (own) {
