@@ -18,46 +18,70 @@ namespace v3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PD_BM = 128, PD_BN = 128, PD_BK = 32, PD_THREADS = 256;
-constexpr int PD_LD = PD_BM + 4;  // padded leading dimension of the k-major LDS tiles
+constexpr int PD_LD = PD_BM;              // k-major LDS tiles [k][row ^ swizzle(k)], 128 floats per k
+constexpr int PD_TILE = PD_BK * PD_LD;    // floats per operand tile (16 KiB)
 
-// Loads a (128 rows x 32 k) slab of a row-major (rows x C) matrix into LDS, transposed to [k][row].
-__device__ __forceinline__ void pd_stage(const float* __restrict__ base, int rows, int C, int row0, int k0,
-                                         bool vec_ok, float* lds) {
-  // 128 rows x 8 float4 per row = 1024 float4; 256 threads x 4
+// A (128 rows x 32 k) slab of a row-major (rows x C) matrix, 4 float4 per thread.  Held in registers between the
+// global load (issued before the MFMA loop of the previous slab) and the transposing LDS store (after it).
+struct PdSlab {
+  float4 v[4];
+};
+// FAST (C % 32 == 0, 16-byte aligned rows): unconditional float4 loads -- rows past the end are clamped to the last
+// row (their results are never stored) so that no load sits behind a branch: hipcc otherwise branches around every
+// guarded load and drains the memory pipe per element.  The generic form handles any C / alignment.
+template <bool FAST>
+__device__ __forceinline__ void pd_load(PdSlab& s, const float* __restrict__ base, int rows, int C, int row0, int k0) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    int f = it * PD_THREADS + threadIdx.x;
-    int r = f >> 3, k4 = (f & 7) * 4;
-    int row = row0 + r, k = k0 + k4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (row < rows) {
-      const float* p = base + (int64_t)row * C + k;
-      if (vec_ok && k + 3 < C) {
-        float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < C) v[e] = p[e];
+    const int f = it * PD_THREADS + threadIdx.x;
+    const int r = f >> 3, k4 = (f & 7) * 4;
+    const int row = row0 + r, k = k0 + k4;
+    if (FAST) {
+      s.v[it] = *reinterpret_cast<const float4*>(base + (int64_t)min(row, rows - 1) * C + k);
+    } else {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows) {
+        const float* p = base + (int64_t)row * C + k;
+        if (k + 0 < C) t.x = p[0];
+        if (k + 1 < C) t.y = p[1];
+        if (k + 2 < C) t.z = p[2];
+        if (k + 3 < C) t.w = p[3];
       }
+      s.v[it] = t;
     }
+  }
+}
+// LDS element (k, r) lives at k*128 + (r ^ (k & ~3)): fragment reads (fixed k, 32 consecutive r) stay conflict-free
+// and the transposing stores of one wave (8 rows x 8 k-groups) spread over all 32 banks (2-way instead of 4-way).
+__device__ __forceinline__ int pd_addr(int k, int r) { return k * PD_LD + (r ^ (k & 28)); }
+__device__ __forceinline__ void pd_store(const PdSlab& s, float* lds) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) lds[(k4 + e) * PD_LD + r] = v[e];
+  for (int it = 0; it < 4; ++it) {
+    const int f = it * PD_THREADS + threadIdx.x;
+    const int r = f >> 3, k4 = (f & 7) * 4;
+    lds[pd_addr(k4 + 0, r)] = s.v[it].x;
+    lds[pd_addr(k4 + 1, r)] = s.v[it].y;
+    lds[pd_addr(k4 + 2, r)] = s.v[it].z;
+    lds[pd_addr(k4 + 3, r)] = s.v[it].w;
   }
 }
 
 // STRICT: the exact difference form sum_c (x_c - y_c)^2 (pairwise_distance.py:28-37) on the VALU, accumulated in
 // the same per-lane output layout as the MFMA path so both share staging and epilogue.
-template <bool STRICT>
+// Pipeline per 32-deep k-slab: the next slab's global loads are issued first and stay in flight under the 64 MFMAs of
+// the current slab; the transposing LDS stores follow between two barriers.  Epilogue: distances go through LDS
+// (reusing the operand tiles) so every lane stores 16 contiguous bytes and a wave 512-byte row segments.
+template <bool STRICT, bool FAST>
 __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ y,
                                                                        float* __restrict__ out, int N, int M, int C,
                                                                        int64_t y_batch_stride, int64_t out_ld,
-                                                                       int flags, float eps, int vec_ok) {
-  __shared__ float xs[PD_BK * PD_LD];
-  __shared__ float ys[PD_BK * PD_LD];
+                                                                       int flags, float eps, int vec_out) {
+  __shared__ __align__(16) float smem[2 * PD_TILE];  // xs | ys, later the 64 x 128 output staging area
   __shared__ float x2s[PD_BM];
   __shared__ float y2s[PD_BN];
+  float* xs = smem;
+  float* ys = smem + PD_TILE;
   const int b = blockIdx.z;
   const int row0 = blockIdx.y * PD_BM, col0 = blockIdx.x * PD_BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,21 +99,28 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
   float norm = 0.f;  // threads 0..127: x row `tid`; 128..255: y row `tid-128`
 
   const int l31 = lane & 31, lh = lane >> 5;
+  PdSlab sx, sy;
+  pd_load<FAST>(sx, xb, N, C, row0, 0);
+  pd_load<FAST>(sy, yb, M, C, col0, 0);
   for (int k0 = 0; k0 < C; k0 += PD_BK) {
+    __syncthreads();  // every wave is done reading the previous slab
+    pd_store(sx, xs);
+    pd_store(sy, ys);
     __syncthreads();
-    pd_stage(xb, N, C, row0, k0, vec_ok, xs);
-    pd_stage(yb, M, C, col0, k0, vec_ok, ys);
-    __syncthreads();
+    if (k0 + PD_BK < C) {  // next slab: in flight while this one is multiplied
+      pd_load<FAST>(sx, xb, N, C, row0, k0 + PD_BK);
+      pd_load<FAST>(sy, yb, M, C, col0, k0 + PD_BK);
+    }
     if (STRICT) {
       for (int k = 0; k < PD_BK; ++k) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const float yv = ys[k * PD_LD + wc * 64 + j * 32 + l31];
+            const float yv = ys[pd_addr(k, wc * 64 + j * 32 + l31)];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float xv = xs[k * PD_LD + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+              const float xv = xs[pd_addr(k, wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh)];
               const float df = xv - yv;
               acc[i][j][r] = __builtin_fmaf(df, df, acc[i][j][r]);
             }
@@ -103,7 +134,7 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
       const int r = tid & 127;
 #pragma unroll
       for (int k = 0; k < PD_BK; ++k) {
-        float v = t[k * PD_LD + r];
+        const float v = t[pd_addr(k, r)];
         norm = __builtin_fmaf(v, v, norm);
       }
     }
@@ -111,18 +142,22 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
     for (int kk = 0; kk < PD_BK; kk += 2) {
       float a[2], bb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = xs[(kk + lh) * PD_LD + wr * 64 + i * 32 + l31];
+      for (int i = 0; i < 2; ++i) a[i] = xs[pd_addr(kk + lh, wr * 64 + i * 32 + l31)];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bb[j] = ys[(kk + lh) * PD_LD + wc * 64 + j * 32 + l31];
+      for (int j = 0; j < 2; ++j) bb[j] = ys[pd_addr(kk + lh, wc * 64 + j * 32 + l31)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+#ifdef V3D_PD_PROBE_NO_MFMA
+          acc[i][j][0] += a[i] * bb[j];  // probe build only: keeps the operands alive without the matrix pipe
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+#endif
     }
   }
   if (tid < 128) x2s[tid] = norm; else y2s[tid - 128] = norm;
-  __syncthreads();
+  __syncthreads();  // norms visible; operand tiles free for the output staging
 
   const bool normalized = flags & V3D_PD_NORMALIZED;
   const bool do_sqrt = flags & V3D_PD_SQRT;
@@ -136,7 +171,8 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
       const float y2 = y2s[cl];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rl = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int r32 = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside the 32 x 32 MFMA tile
+        const int rl = wr * 64 + i * 32 + r32;
         const int row = row0 + rl;
         const float xy = acc[i][j][r];
         float d;
@@ -147,22 +183,52 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
           d = fmaxf(d, 0.0f);                                                   // :53
           if (do_sqrt) d = sqrtf(d + eps);                                      // :56
         }
-        if (row < N && col < M) ob[(int64_t)row * out_ld + col] = d;
+        if (vec_out) {
+          smem[(wr * 32 + r32) * PD_BN + cl] = d;  // staging row = 32*wr + r32 for this i
+        } else {
+#ifdef V3D_PD_PROBE_NO_STORE
+          if (row < N && col < M && d == 12345.f) ob[(int64_t)row * out_ld + col] = d;  // probe build only
+#else
+          if (row < N && col < M) ob[(int64_t)row * out_ld + col] = d;
+#endif
+        }
       }
+    }
+    if (vec_out) {  // 64 rows x 128 columns staged: 8 float4 per thread, 512 contiguous bytes per row
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int f = it * PD_THREADS + tid;
+        const int srow = f >> 5, c4 = (f & 31) * 4;
+        const int row = row0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
+        const int col = col0 + c4;
+        if (row < N && col < M) {  // M % 4 == 0 here, so col < M covers the whole vector
+          const float4 v = *reinterpret_cast<const float4*>(&smem[srow * PD_BN + c4]);
+#ifdef V3D_PD_PROBE_NO_STORE
+          if (v.x == 12345.f)
+#endif
+          *reinterpret_cast<float4*>(&ob[(int64_t)row * out_ld + col]) = v;
+        }
+      }
+      __syncthreads();
     }
   }
 }
 
 static int launch_pairwise(const float* x, const float* y, float* out, int batch, int N, int M, int C,
-                           int64_t out_ld, int flags, float eps, hipStream_t stream) {
-  const int vec_ok = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+                           int64_t y_batch_stride, int64_t out_ld, int flags, float eps, hipStream_t stream) {
+  const bool fast = (C % PD_BK == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && N > 0 && M > 0;
+  const int vec_out = (M % 4 == 0) && (out_ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
   dim3 grid((unsigned)ceil_div(M, PD_BN), (unsigned)ceil_div(N, PD_BM), (unsigned)batch);
-  if (flags & V3D_PD_STRICT)
-    hipLaunchKernelGGL(pairwise_distance_kernel<true>, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C,
-                       (int64_t)M * C, out_ld, flags, eps, vec_ok);
-  else
-    hipLaunchKernelGGL(pairwise_distance_kernel<false>, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C,
-                       (int64_t)M * C, out_ld, flags, eps, vec_ok);
+#define V3D_LAUNCH_PD(S_, F_)                                                                                   \
+  hipLaunchKernelGGL((pairwise_distance_kernel<S_, F_>), grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C, \
+                     y_batch_stride, out_ld, flags, eps, vec_out)
+  if (flags & V3D_PD_STRICT) {
+    if (fast) V3D_LAUNCH_PD(true, true); else V3D_LAUNCH_PD(true, false);
+  } else {
+    if (fast) V3D_LAUNCH_PD(false, true); else V3D_LAUNCH_PD(false, false);
+  }
+#undef V3D_LAUNCH_PD
   return launch_status("pairwise_distance");
 }
 
@@ -187,8 +253,29 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
     ld_ = run_d[row * k + lane];
     li = run_i[row * k + lane];
   }
-  float tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1));
   const float* drow = D + row * ld;
+  // Pre-pass (first chunk of a row only, when the list is still empty): every lane takes the minimum of its own
+  // columns; the k-th smallest of those 64 minima is an upper bound of the row's k-th smallest distance, usually a
+  // tight one, and caps the insertion threshold from the start (an empty list would otherwise admit every column
+  // of the first chunks).  Costs one extra read of the row (L2 / Infinity-Cache resident).
+  float cap = INFINITY;
+  if (first_chunk && ncols >= 256) {
+    float lmin = INFINITY;
+    for (int c0 = 0; c0 < ncols; c0 += 64) {
+      const int c = c0 + lane;
+      lmin = fminf(lmin, c < ncols ? drow[c] : INFINITY);
+    }
+    int rank = 0;
+    for (int o = 0; o < 64; ++o) {
+      const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmin), o));
+      rank += (v < lmin || (v == lmin && o < lane)) ? 1 : 0;
+    }
+    const unsigned long long sel = __ballot(rank == k - 1);  // ranks are a permutation: exactly one lane
+    const float kth = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmin), __builtin_ffsll((long long)sel) - 1));
+    // strict '<' below must still admit values equal to the bound: step to the next float (kth >= 0)
+    cap = kth < INFINITY ? __uint_as_float(__float_as_uint(kth) + 1u) : INFINITY;
+  }
+  float tau = fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1)), cap);
   for (int c0 = 0; c0 < ncols; c0 += 64) {
     const int c = c0 + lane;
     const float d = c < ncols ? drow[c] : INFINITY;
@@ -209,7 +296,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
         ld_ = cd;
         li = ci;
       }
-      tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1));
+      tau = fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1)), cap);
       m = __ballot(d < tau) & ~((2ull << l) - 1ull);
     }
   }
@@ -219,8 +306,22 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
+#define V3D_DPP_ADD(v, CTRL_TEXT) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTRL_TEXT : "+v"(v))
+__device__ __forceinline__ float wave_sum_f32(float v) {  // sum over the 64 lanes, wave-uniform result
+  V3D_DPP_ADD(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_ADD(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_ADD(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+  V3D_DPP_ADD(v, "row_mirror row_mask:0xf bank_mask:0xf");
+  V3D_DPP_ADD(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  V3D_DPP_ADD(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  asm volatile("s_nop 1" ::: "memory");
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Final pass: recompute the k selected distances exactly as sqrt(sum_c (x_c - y_c)^2) (what pykeops evaluates,
 // ops/knn.py:25), re-rank by (distance, index) and write fp32 distances + int64 (offset) indices.
+// One wave per query row; for each selected neighbour the 64 lanes split the channels (coalesced row reads) and
+// reduce with a DPP butterfly, lane j keeps neighbour j's distance.
 __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                 const float* __restrict__ run_d,
                                                                 const int* __restrict__ run_i, int batch, int N, int M,
@@ -230,17 +331,20 @@ __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __r
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (int64_t)batch * N) return;
   const int b = (int)(row / N);
-  int idx = lane < k ? run_i[row * k + lane] : -1;
+  const int idx = lane < k ? run_i[row * k + lane] : -1;
   float dist = INFINITY;
-  if (idx >= 0) {
-    const float* xr = x + row * C;
-    const float* yr = y + ((int64_t)b * M + idx) * C;
-    float acc = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float df = xr[c] - yr[c];
-      acc = __builtin_fmaf(df, df, acc);
+  const float* xr = x + row * C;
+  for (int j = 0; j < k; ++j) {
+    const int ij = __builtin_amdgcn_readlane(idx, j);  // wave-uniform
+    if (ij < 0) continue;
+    const float* yr = y + ((int64_t)b * M + ij) * C;
+    float part = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float df = xr[c] - yr[c];
+      part = __builtin_fmaf(df, df, part);
     }
-    dist = sqrtf(acc);
+    const float tot = wave_sum_f32(part);
+    if (lane == j) dist = sqrtf(tot);
   }
   // rank sort among the k entries (k <= 64): position = number of entries that precede mine
   int rank = 0;
@@ -344,7 +448,8 @@ int v3d_pairwise_distance_f32(const float* x, const float* y, float* out, int ba
   }
   DeviceGuard guard(device);
   if (guard.rc) return guard.rc;
-  return launch_pairwise(x, y, out, batch, N, M, C, (int64_t)M, flags, eps, static_cast<hipStream_t>(stream_));
+  return launch_pairwise(x, y, out, batch, N, M, C, (int64_t)M * C, (int64_t)M, flags, eps,
+                         static_cast<hipStream_t>(stream_));
 }
 
 size_t v3d_knn_feat_workspace_bytes(int batch, int N, int M, int C, int k) {
@@ -393,14 +498,8 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
     const int mc = std::min(ws.mc, M - m0);
     // distances of every row of every batch against columns [m0, m0+mc): batch b uses y + (b*M + m0)*C
     const float* ychunk = y + (int64_t)m0 * C;
-    {
-      const int vec_ok = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)ychunk % 16 == 0);
-      dim3 grid((unsigned)ceil_div(mc, PD_BN), (unsigned)ceil_div(N, PD_BM), (unsigned)batch);
-      // only mc columns are visited per cloud, but consecutive clouds of y stay M*C apart
-      hipLaunchKernelGGL(pairwise_distance_kernel<false>, grid, dim3(PD_THREADS), 0, stream, x, ychunk, ws.chunk, N, mc, C,
-                         (int64_t)M * C, (int64_t)ws.mc, 0, 0.f, vec_ok);
-      rc = launch_status(what);
-    }
+    // only mc columns are visited per cloud, but consecutive clouds of y stay M*C apart
+    rc = launch_pairwise(x, ychunk, ws.chunk, batch, N, mc, C, (int64_t)M * C, (int64_t)ws.mc, 0, 0.f, stream);
     if (rc) break;
     hipLaunchKernelGGL(topk_rows_kernel, dim3(row_blocks), dim3(256), 0, stream, ws.chunk, rows, mc, (int64_t)ws.mc,
                        m0, k, m0 == 0 ? 1 : 0, ws.run_d, ws.run_i);

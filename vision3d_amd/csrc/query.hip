@@ -8,10 +8,12 @@
 //                  as its queries are full.
 //   * three_nn   : one thread per query, supports broadcast from LDS as 16-byte points, branch-free
 //                  strict-< insertion cascade (ties keep the lower index first, like the reference).
-//   * knn_points : one wave per query.  Lanes evaluate 64 supports at a time and ballot those that beat the
-//                  heap root; only those are replayed, in index order, through the reference's max-heap
-//                  (kept in LDS, sifted by the whole wave with uniform addresses), so ties leave the heap in
-//                  exactly the reference's order.
+//   * knn_points : one wave per group of 4 queries.  Lanes evaluate 64 supports at a time; per query the k+1 best
+//                  so far live sorted, one entry per lane, and a chunk is filtered by one compare + ballot against
+//                  the (k+1)-th best; survivors are inserted with a whole-wave DPP shift.  If the final k+1
+//                  distances are all different the reference's heap can only yield this list; otherwise (exact
+//                  ties) that query is replayed through the reference's max-heap (LDS, wave-uniform sifts), so
+//                  ties come out in exactly the reference's order.
 // Squared distances use the reference's expression order with one rounding per operation (the library is
 // compiled with -ffp-contract=off).
 #include <type_traits>
@@ -300,34 +302,141 @@ __device__ __forceinline__ void heap_sift(HeapSlot<T>* h, int size, T vd, int vi
   h[root] = v;
 }
 
-template <typename T, int QPW, int TS>
+// ---- lane-distributed sorted list (ascending by (distance, arrival)), CAP = 64*R entries ----------------------
+__device__ __forceinline__ int shr1_fill(int v, int fill) {  // lane l <- lane l-1, lane 0 <- fill
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float shr1_fill(float v, float fill) {
+  return __int_as_float(shr1_fill(__float_as_int(v), __float_as_int(fill)));
+}
+__device__ __forceinline__ double shr1_fill(double v, double fill) {
+  const long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
+  const int lo = shr1_fill((int)(b & 0xffffffffll), (int)(f & 0xffffffffll));
+  const int hi = shr1_fill((int)(b >> 32), (int)(f >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane_permute(float v, int dst_lane) {  // lane l sends v to lane dst_lane
+  return __int_as_float(__builtin_amdgcn_ds_permute(dst_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int lane_permute(int v, int dst_lane) { return __builtin_amdgcn_ds_permute(dst_lane << 2, v); }
+__device__ __forceinline__ double lane_permute(double v, int dst_lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_permute(dst_lane << 2, (int)(b & 0xffffffffll));
+  const int hi = __builtin_amdgcn_ds_permute(dst_lane << 2, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T, int R>
+struct LaneList {
+  T d[R];
+  int i[R];
+  __device__ __forceinline__ void insert(T cd, int ci, int lane) {
+    int pos = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) pos += __builtin_popcountll(__ballot(d[r] <= cd));  // equal keys: earlier arrival first
+    T carry_d = cd;  // value entering register r at its lane 0 when everything shifts
+    int carry_i = ci;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int lp = pos - 64 * r;  // insertion lane inside register r (may be < 0: all shift, >= 64: untouched)
+      const T last_d = read_lane(d[r], 63);
+      const int last_i = __builtin_amdgcn_readlane(i[r], 63);
+      const T sd = shr1_fill(d[r], carry_d);
+      const int si = shr1_fill(i[r], carry_i);
+      const bool take_new = lane == lp;
+      const bool take_shift = lane > lp;
+      d[r] = take_new ? cd : (take_shift ? sd : d[r]);
+      i[r] = take_new ? ci : (take_shift ? si : i[r]);
+      carry_d = last_d;
+      carry_i = last_i;
+    }
+  }
+  __device__ __forceinline__ T at(int rank) const {  // rank is wave-uniform
+    T v = read_lane(d[0], rank & 63);
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      const T o = read_lane(d[r], rank & 63);
+      v = (rank >> 6) == r ? o : v;
+    }
+    return v;
+  }
+};
+
+// Exact replay of the reference heap for ONE query by the whole wave (used only when the fast path sees equal
+// distances among the k+1 nearest, where the heap's mechanics decide identity and order): supports are read from
+// global memory (L2-resident), candidates that beat the root are replayed in index order.
+template <typename T>
+__device__ void knn_exact_replay(const T* __restrict__ s_cloud, int N, int k, T qx, T qy, T qz, HeapSlot<T>* h,
+                                 T* __restrict__ od, int64_t* __restrict__ oi) {
+  const int lane = threadIdx.x & 63;
+  for (int n = lane; n < k; n += 64) {  // knn_points_cuda.cuh:70-73
+    HeapSlot<T> v;
+    v.d = static_cast<T>(1e10);
+    v.i = 0;
+    h[n] = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  T root_d = static_cast<T>(1e10);
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int j = c0 + lane;
+    const bool valid = j < N;
+    const int jj = valid ? j : 0;
+    const T d = sq_dist(qx, qy, qz, s_cloud[(int64_t)jj * 3 + 0], s_cloud[(int64_t)jj * 3 + 1],
+                        s_cloud[(int64_t)jj * 3 + 2]);
+    unsigned long long m = __ballot(valid && d < root_d);  // :80 strict
+    while (m) {
+      const int l = __builtin_ffsll((long long)m) - 1;
+      heap_sift(h, k, read_lane(d, l), c0 + l);
+      root_d = h[0].d;
+      m = __ballot(valid && d < root_d) & ~((2ull << l) - 1ull);
+    }
+  }
+  for (int i = k - 1; i > 0; --i) {  // heap_sort :30-37
+    const HeapSlot<T> top = h[0];
+    const HeapSlot<T> last = h[i];
+    h[i] = top;
+    heap_sift(h, i, last.d, last.i);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int n = lane; n < k; n += 64) {  // :88-91
+    const HeapSlot<T> v = h[n];
+    od[n] = sqrt(v.d);
+    oi[n] = (int64_t)v.i;
+  }
+}
+
+// Fast path: one wave serves QPW queries against LDS-staged supports.  Per query the k+1 best so far sit sorted in a
+// lane-distributed list; a chunk of 64 supports is filtered with one compare + ballot against the (k+1)-th best and
+// only the survivors are inserted (whole-wave DPP shift).  When the final k+1 distances are pairwise different the
+// reference heap can only produce this very list; otherwise the query is replayed through the exact heap.
+template <typename T, int R, int QPW, int TS>
 __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __restrict__ q, const T* __restrict__ s,
                                                                    T* __restrict__ out_d, int64_t* __restrict__ out_i,
                                                                    int M, int N, int k) {
   __shared__ T tile[TS * 3];
-  __shared__ HeapSlot<T> heaps[kWavesPerBlock * QPW * V3D_KNN_MAX_K];
+  __shared__ HeapSlot<T> heaps[kWavesPerBlock * V3D_KNN_MAX_K];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q_first = (blockIdx.x * kWavesPerBlock + wave) * QPW;
   const T* s_cloud = s + (int64_t)b * N * 3;
-  HeapSlot<T>* my_heaps = heaps + wave * QPW * V3D_KNN_MAX_K;
+  const T sentinel = static_cast<T>(1e10);  // knn_points_cuda.cuh:71: nothing >= 1e10 ever enters
 
-  T qx[QPW], qy[QPW], qz[QPW], root_d[QPW];
+  T qx[QPW], qy[QPW], qz[QPW], tau[QPW];
+  LaneList<T, R> list[QPW];
 #pragma unroll
   for (int g = 0; g < QPW; ++g) {
-    int qi = q_first + g;
-    bool live = qi < M;
+    const int qi = q_first + g;
+    const bool live = qi < M;
     const T* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
     qx[g] = qp[0];
     qy[g] = qp[1];
     qz[g] = qp[2];
-    root_d[g] = live ? static_cast<T>(1e10) : static_cast<T>(-1);  // dead slot: nothing ever beats -1
-    for (int n = lane; n < k; n += 64) {  // knn_points_cuda.cuh:70-73
-      HeapSlot<T> v;
-      v.d = static_cast<T>(1e10);
-      v.i = 0;
-      my_heaps[g * V3D_KNN_MAX_K + n] = v;
+    tau[g] = live ? sentinel : static_cast<T>(-1);  // dead slot: nothing ever beats -1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      list[g].d[r] = sentinel;
+      list[g].i[r] = 0;
     }
   }
 
@@ -341,40 +450,62 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
       const bool valid = j < tcount;
       const int jj = valid ? j : 0;
       const T sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+      const bool first_chunk = (t0 == 0 && c0 == 0);
 #pragma unroll
       for (int g = 0; g < QPW; ++g) {
-        HeapSlot<T>* h = my_heaps + g * V3D_KNN_MAX_K;
         const T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
-        unsigned long long m = __ballot(valid && d < root_d[g]);  // :80 strict
-        while (m) {  // replay the candidates in index order
+        if (first_chunk && tau[g] == sentinel) {
+          // empty list: rank-sort the whole chunk straight into it instead of 64 serial insertions
+          const bool real = valid && d < sentinel;
+          const T dm = real ? d : sentinel;
+          const int im = real ? j : 0;
+          int rank = 0;
+          for (int o = 0; o < 64; ++o) {
+            const T dv = read_lane(dm, o);
+            rank += (dv < dm || (dv == dm && o < lane)) ? 1 : 0;
+          }
+          list[g].d[0] = lane_permute(dm, rank);
+          list[g].i[0] = lane_permute(im, rank);
+          tau[g] = list[g].at(k);
+          continue;
+        }
+        unsigned long long m = __ballot(valid && d < tau[g]);
+        while (m) {
           const int l = __builtin_ffsll((long long)m) - 1;
-          const T dl = read_lane(d, l);
-          heap_sift(h, k, dl, t0 + c0 + l);
-          root_d[g] = h[0].d;
-          const unsigned long long above = ~((2ull << l) - 1ull);
-          m = __ballot(valid && d < root_d[g]) & above;
+          list[g].insert(read_lane(d, l), t0 + c0 + l, lane);
+          tau[g] = list[g].at(k);
+          m = __ballot(valid && d < tau[g]) & ~((2ull << l) - 1ull);
         }
       }
     }
   }
 
-  // heap_sort (knn_points_cuda.cuh:30-37) then the coalesced write-out with sqrt (:88-91)
 #pragma unroll
   for (int g = 0; g < QPW; ++g) {
     if (q_first + g >= M) continue;
-    HeapSlot<T>* h = my_heaps + g * V3D_KNN_MAX_K;
-    for (int i = k - 1; i > 0; --i) {
-      HeapSlot<T> top = h[0];
-      HeapSlot<T> last = h[i];
-      h[i] = top;
-      heap_sift(h, i, last.d, last.i);
-    }
     T* od = out_d + ((int64_t)b * M + q_first + g) * k;
     int64_t* oi = out_i + ((int64_t)b * M + q_first + g) * k;
-    for (int n = lane; n < k; n += 64) {
-      HeapSlot<T> v = h[n];
-      od[n] = sqrt(v.d);
-      oi[n] = (int64_t)v.i;
+    // equal real distances among ranks 0..k -> the heap's mechanics matter
+    unsigned long long ties = 0ull;
+    T prev_last = static_cast<T>(-1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const T below = shr1_fill(list[g].d[r], prev_last);
+      const int rank = 64 * r + lane;
+      ties |= __ballot(rank >= 1 && rank <= k && list[g].d[r] == below && list[g].d[r] < sentinel);
+      prev_last = read_lane(list[g].d[r], 63);
+    }
+    if (ties != 0ull) {
+      knn_exact_replay(s_cloud, N, k, qx[g], qy[g], qz[g], heaps + wave * V3D_KNN_MAX_K, od, oi);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int rank = 64 * r + lane;
+        if (rank < k) {
+          od[rank] = sqrt(list[g].d[r]);  // :90
+          oi[rank] = (int64_t)list[g].i[r];
+        }
+      }
     }
   }
 }
@@ -400,7 +531,10 @@ static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, 
   constexpr int QPW = 4;
   constexpr int TS = 1024;
   dim3 grid((unsigned)ceil_div(M, kWavesPerBlock * QPW), (unsigned)B), block(kQueryThreads);
-  hipLaunchKernelGGL((knn_points_kernel<T, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
+  if (k + 1 <= 64)  // the list holds the k+1 best: one or two entries per lane
+    hipLaunchKernelGGL((knn_points_kernel<T, 1, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
+  else
+    hipLaunchKernelGGL((knn_points_kernel<T, 2, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
   return launch_status(what);
 }
 
