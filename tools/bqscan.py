@@ -1,0 +1,12 @@
+import sys, os, torch, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from vision3d_amd import ext
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
+from opbench import timeit
+g = torch.Generator().manual_seed(0)
+for (B, N, M, k, r) in ((32, 64, 1024, 16, 0.1), (32, 1024, 1024, 16, 0.1), (32, 2048, 1024, 16, 0.1), (32, 4096, 1024, 16, 0.1), (32, 4096, 1024, 16, 0.0001), (32, 4096, 1024, 16, 2.0), (32, 8192, 1024, 16, 0.1), (32, 4096, 4096, 16, 0.1)):
+    pts = torch.rand((B, N, 3), generator=g).cuda()
+    q = torch.rand((B, M, 3), generator=g).cuda()
+    bi = torch.zeros((B, M, k), dtype=torch.long, device="cuda")
+    med, mn = timeit(lambda: ext.ball_query(q, pts, bi, r, k))
+    print(f"B{B} N{N} M{M} k{k} r{r}: {med*1e3:.1f} us (min {mn*1e3:.1f})")

@@ -27,6 +27,64 @@ struct alignas(sizeof(E) * VEC) Pack {
 
 constexpr int kGatherThreads = 256;
 
+// XCD-aware workgroup placement.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with a private
+// 4 MiB L2.  All position tiles and channel tiles of one cloud re-read that cloud's source rows and indices, so the
+// launch is a 1-D grid decoded such that every workgroup of a cloud (mode 1, B % 8 == 0) or of a (cloud, channel
+// tile) pair (mode 2) carries the same id % 8: the rows are then fetched from HBM by ONE L2 instead of eight.
+// Placement is a speed matter only; any mapping gives the same result.
+struct GridMap {
+  int X, Y, mode;
+};
+__device__ __forceinline__ void decode_block(const GridMap g, int& bx, int& by, int& bz) {
+  const unsigned id = blockIdx.x;
+  if (g.mode == 0) {
+    bx = id % g.X;
+    by = (id / g.X) % g.Y;
+    bz = id / (g.X * g.Y);
+  } else {
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    if (g.mode == 1) {
+      const unsigned per_b = g.X * g.Y;
+      bz = (slot / per_b) * 8 + xcd;
+      const unsigned rem = slot % per_b;
+      bx = rem % g.X;
+      by = rem / g.X;
+    } else {
+      const unsigned grp = (slot / g.X) * 8 + xcd;
+      bx = slot % g.X;
+      by = grp % g.Y;
+      bz = grp / g.Y;
+    }
+  }
+}
+static GridMap make_grid_map(int64_t X, int64_t Y, int64_t B) {
+  GridMap g;
+  g.X = (int)X;
+  g.Y = (int)Y;
+  g.mode = (B % 8 == 0) ? 1 : ((B * Y) % 8 == 0 ? 2 : 0);
+  return g;
+}
+
+// Streaming store of one packed vector: the gathered output is written once and never re-read by this kernel, so it
+// is stored non-temporally (V3D_GATHER_NT=0 switches to plain stores; tuning aid).
+template <typename E, int VEC>
+__device__ __forceinline__ void store_pack(E* dst, const Pack<E, VEC>& pk, bool nt) {
+  constexpr int kBytes = sizeof(E) * VEC;
+  if (nt) {
+    if constexpr (kBytes == 16) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&pk), reinterpret_cast<u32x4*>(dst));
+    } else if constexpr (kBytes == 8) {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&pk), reinterpret_cast<u32x2*>(dst));
+    } else {
+      __builtin_nontemporal_store(*reinterpret_cast<const unsigned int*>(&pk), reinterpret_cast<unsigned int*>(dst));
+    }
+  } else {
+    *reinterpret_cast<Pack<E, VEC>*>(dst) = pk;
+  }
+}
+
 // Index fetch with the reference's long -> int narrowing (group_gather_cuda.cuh:30); out-of-range values
 // (undefined behaviour in the reference) are mapped to -1 and produce zeros instead of a fault.
 __device__ __forceinline__ int fetch_index(const int64_t* __restrict__ idx, int64_t pos, int64_t limit, int N) {
@@ -39,23 +97,24 @@ __device__ __forceinline__ int fetch_index(const int64_t* __restrict__ idx, int6
 // tileable are staged element-wise).  Row buffers hold N+1 elements: slot N is a zero that out-of-range
 // indices are redirected to, so the gather loop carries no per-element range check.  Requires 16-byte stores
 // (L % VEC == 0, aligned output); everything else takes the direct kernel.
-template <typename E, int VEC, int R, int NSTAGE>
-__global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
+template <typename E, int VEC, int R, int NSTAGE, int T>
+__global__ __launch_bounds__(T) void gather_fwd_lds_kernel(
     const E* __restrict__ src, const int64_t* __restrict__ idx, E* __restrict__ out, int C, int N, int64_t L,
-    int CT, int buf_elems) {
+    int CT, int buf_elems, int nt, GridMap gm) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   E* smem = reinterpret_cast<E*>(smem_raw);
   const int tid = threadIdx.x;
-  const int b = blockIdx.z;
-  const int c0 = blockIdx.y * CT;
+  int bx, by, b;
+  decode_block(gm, bx, by, b);
+  const int c0 = by * CT;
   const int c1 = min(c0 + CT, C);
-  const int64_t tile0 = (int64_t)blockIdx.x * (kGatherThreads * VEC * R);
+  const int64_t tile0 = (int64_t)bx * (T * VEC * R);
 
   int my[R][VEC];
   const int64_t* bidx = idx + (int64_t)b * L;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
+    int64_t p0 = tile0 + ((int64_t)r * T + tid) * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       int v = fetch_index(bidx, p0 + e, L, N);
@@ -77,11 +136,11 @@ __global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
       uint4* dst4 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
       for (int i = 0; i < NSTAGE; ++i) {
-        int v = i * kGatherThreads + tid;
+        int v = i * T + tid;
         if (v < nvec) dst4[v] = row4[v];
       }
     } else {
-      for (int i = tid; i < N; i += kGatherThreads) smem[i] = row[i];
+      for (int i = tid; i < N; i += T) smem[i] = row[i];
     }
   }
   for (int c = c0; c < c1; ++c) {
@@ -95,19 +154,19 @@ __global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
       const uint4* row4 = reinterpret_cast<const uint4*>(nrow);
 #pragma unroll
       for (int i = 0; i < NSTAGE; ++i) {
-        int v = i * kGatherThreads + tid;
+        int v = i * T + tid;
         stg[i] = (have_next && v < nvec) ? row4[v] : make_uint4(0, 0, 0, 0);
       }
     }
     E* orow = out + ((int64_t)b * C + c) * L;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
+      int64_t p0 = tile0 + ((int64_t)r * T + tid) * VEC;
       if (p0 < L) {
         Pack<E, VEC> pk;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) pk.v[e] = cur[my[r][e]];
-        *reinterpret_cast<Pack<E, VEC>*>(orow + p0) = pk;
+        store_pack<E, VEC>(orow + p0, pk, nt);
       }
     }
     if (have_next) {
@@ -115,11 +174,11 @@ __global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
         uint4* dst4 = reinterpret_cast<uint4*>(nxt);
 #pragma unroll
         for (int i = 0; i < NSTAGE; ++i) {
-          int v = i * kGatherThreads + tid;
+          int v = i * T + tid;
           if (v < nvec) dst4[v] = stg[i];
         }
       } else {
-        for (int i = tid; i < N; i += kGatherThreads) nxt[i] = nrow[i];
+        for (int i = tid; i < N; i += T) nxt[i] = nrow[i];
       }
     }
   }
@@ -128,12 +187,13 @@ __global__ __launch_bounds__(kGatherThreads) void gather_fwd_lds_kernel(
 template <typename E, int VEC, int R, bool VEC_STORE>
 __global__ __launch_bounds__(kGatherThreads) void gather_fwd_direct_kernel(
     const E* __restrict__ src, const int64_t* __restrict__ idx, E* __restrict__ out, int C, int N, int64_t L,
-    int CT) {
+    int CT, GridMap gm) {
   const int tid = threadIdx.x;
-  const int b = blockIdx.z;
-  const int c0 = blockIdx.y * CT;
+  int bx, by, b;
+  decode_block(gm, bx, by, b);
+  const int c0 = by * CT;
   const int c1 = min(c0 + CT, C);
-  const int64_t tile0 = (int64_t)blockIdx.x * (kGatherThreads * VEC * R);
+  const int64_t tile0 = (int64_t)bx * (kGatherThreads * VEC * R);
   int my[R][VEC];
   const int64_t* bidx = idx + (int64_t)b * L;
 #pragma unroll
@@ -184,42 +244,56 @@ static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, i
   const size_t row_bytes = (size_t)N * sizeof(E);
   const bool row_vec_ok = (row_bytes % 16 == 0) && ((uintptr_t)src % 16 == 0);
   const int buf_elems = (int)(align_up(row_bytes + sizeof(E), 16) / sizeof(E));  // N + zero slot, 16-B multiple
-  // positions per workgroup: R vectors of VEC per thread
+  // positions per workgroup: T threads x R vectors of VEC (512- and 1024-thread tiles were measured: no gain).
   constexpr int R_BIG = 8, R_SMALL = 2;
-  const bool big = L >= (int64_t)kGatherThreads * VEC * R_BIG;
-  const int R = big ? R_BIG : R_SMALL;
-  const int64_t xblocks = ceil_div(L, (int64_t)kGatherThreads * VEC * R);
-  // channel tile: as large as possible (index reuse, staging amortisation) while keeping >= ~2048 workgroups
-  int CT = 16;
-  while (CT > 2 && xblocks * ceil_div(C, CT) * B < 2048) CT >>= 1;
-  if (CT > C) CT = C;
   const int mode = gather_mode_override();
+  static const int nt = getenv("V3D_GATHER_NT") ? atoi(getenv("V3D_GATHER_NT")) : 1;
   const bool lds_fits = row_bytes <= 32768;
-  bool use_lds = vec_store && lds_fits && (int64_t)N * 2 <= (int64_t)kGatherThreads * VEC * R * CT;
+  int T = kGatherThreads, R = R_SMALL, CT = 16;
+  int64_t xblocks = 0;
+  auto plan = [&](int threads) {
+    T = threads;
+    R = (L >= (int64_t)T * VEC * R_BIG) ? R_BIG : R_SMALL;
+    xblocks = ceil_div(L, (int64_t)T * VEC * R);
+    // channel tile: as large as possible (index reuse, staging amortisation) while keeping >= ~8192 waves
+    CT = 16;
+    while (CT > 2 && xblocks * ceil_div(C, CT) * B * (T / 64) < 8192) CT >>= 1;
+    if (CT > C) CT = C;
+  };
+  plan(kGatherThreads);
+  bool use_lds = vec_store && lds_fits && (int64_t)N * 2 <= (int64_t)T * VEC * R * CT;
   if (mode == 1) use_lds = vec_store && lds_fits;
   if (mode == 2) use_lds = false;
-  dim3 grid((unsigned)xblocks, (unsigned)ceil_div(C, CT), (unsigned)B);
-  dim3 block(kGatherThreads);
+  const int64_t yblocks = ceil_div(C, CT);
+  if (xblocks * yblocks * B > (int64_t)INT32_MAX) {
+    set_last_error("gather_forward: launch of %lld workgroups exceeds the grid limit", (long long)(xblocks * yblocks * B));
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  const GridMap gm = make_grid_map(xblocks, yblocks, B);
+  dim3 grid((unsigned)(xblocks * yblocks * B));
+  dim3 block(T);
   if (use_lds) {
     const size_t lds = 2 * (size_t)buf_elems * sizeof(E);
-    const int nvec_per_thread = row_vec_ok ? (int)ceil_div((int64_t)(row_bytes / 16), kGatherThreads) : 0;
-#define V3D_LAUNCH_LDS(RR, NS)                                                                               \
-  hipLaunchKernelGGL((gather_fwd_lds_kernel<E, VEC, RR, NS>), grid, block, lds, stream, src, idx, out, C, N, L, \
-                     CT, buf_elems)
-#define V3D_LAUNCH_LDS_R(RR)                         \
-  do {                                               \
-    if (nvec_per_thread == 0) V3D_LAUNCH_LDS(RR, 0); \
-    else if (nvec_per_thread <= 1) V3D_LAUNCH_LDS(RR, 1); \
-    else if (nvec_per_thread <= 4) V3D_LAUNCH_LDS(RR, 4); \
-    else V3D_LAUNCH_LDS(RR, 8);                      \
+    const int nvec_per_thread = row_vec_ok ? (int)ceil_div((int64_t)(row_bytes / 16), T) : 0;
+#define V3D_LAUNCH_LDS(RR, NS, TT)                                                                                 \
+  hipLaunchKernelGGL((gather_fwd_lds_kernel<E, VEC, RR, NS, TT>), grid, block, lds, stream, src, idx, out, C, N, L, \
+                     CT, buf_elems, nt, gm)
+    {
+#define V3D_LAUNCH_LDS_R(RR)                                     \
+  do {                                                           \
+    if (nvec_per_thread == 0) V3D_LAUNCH_LDS(RR, 0, 256);        \
+    else if (nvec_per_thread <= 1) V3D_LAUNCH_LDS(RR, 1, 256);   \
+    else if (nvec_per_thread <= 4) V3D_LAUNCH_LDS(RR, 4, 256);   \
+    else V3D_LAUNCH_LDS(RR, 8, 256);                             \
   } while (0)
-    if (big) V3D_LAUNCH_LDS_R(R_BIG); else V3D_LAUNCH_LDS_R(R_SMALL);
+      if (R == R_BIG) V3D_LAUNCH_LDS_R(R_BIG); else V3D_LAUNCH_LDS_R(R_SMALL);
 #undef V3D_LAUNCH_LDS_R
+    }
 #undef V3D_LAUNCH_LDS
   } else {
 #define V3D_LAUNCH_DIRECT(RR, VS) \
-  hipLaunchKernelGGL((gather_fwd_direct_kernel<E, VEC, RR, VS>), grid, block, 0, stream, src, idx, out, C, N, L, CT)
-    if (big) {
+  hipLaunchKernelGGL((gather_fwd_direct_kernel<E, VEC, RR, VS>), grid, block, 0, stream, src, idx, out, C, N, L, CT, gm)
+    if (R == R_BIG) {
       if (vec_store) V3D_LAUNCH_DIRECT(R_BIG, true); else V3D_LAUNCH_DIRECT(R_BIG, false);
     } else {
       if (vec_store) V3D_LAUNCH_DIRECT(R_SMALL, true); else V3D_LAUNCH_DIRECT(R_SMALL, false);

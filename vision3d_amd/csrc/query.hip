@@ -31,6 +31,24 @@ __device__ __forceinline__ T sq_dist(T qx, T qy, T qz, T sx, T sy, T sz) {
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// Two queries against one support in packed fp32 (v_pk_add_f32 / v_pk_mul_f32: per-element IEEE results identical
+// to the scalar form, half the instructions); the double variant is two scalar evaluations.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sq_dist_pair(float qx0, float qy0, float qz0, float qx1, float qy1, float qz1, float sx,
+                                             float sy, float sz, float& d0, float& d1) {
+  const f32x2_t dx = f32x2_t{qx0, qx1} - f32x2_t{sx, sx};
+  const f32x2_t dy = f32x2_t{qy0, qy1} - f32x2_t{sy, sy};
+  const f32x2_t dz = f32x2_t{qz0, qz1} - f32x2_t{sz, sz};
+  const f32x2_t d = (dx * dx + dy * dy) + dz * dz;
+  d0 = d[0];
+  d1 = d[1];
+}
+__device__ __forceinline__ void sq_dist_pair(double qx0, double qy0, double qz0, double qx1, double qy1, double qz1,
+                                             double sx, double sy, double sz, double& d0, double& d1) {
+  d0 = sq_dist(qx0, qy0, qz0, sx, sy, sz);
+  d1 = sq_dist(qx1, qy1, qz1, sx, sy, sz);
+}
+
 __device__ __forceinline__ float read_lane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -46,7 +64,43 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
 template <typename T>
 __device__ __forceinline__ void stage_supports_aos(const T* __restrict__ s_cloud, int first, int count, T* lds) {
   const T* g = s_cloud + (int64_t)first * 3;
-  for (int i = threadIdx.x; i < count * 3; i += blockDim.x) lds[i] = g[i];
+  const int nbytes = count * 3 * (int)sizeof(T);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    // 16-byte copies, eight in flight per thread before the first LDS store (a one-load-one-store loop would pay
+    // the full L2 latency per iteration)
+    const uint4* g4 = reinterpret_cast<const uint4*>(g);
+    uint4* l4 = reinterpret_cast<uint4*>(lds);
+    const int nvec = nbytes >> 4;
+    for (int base = 0; base < nvec; base += 8 * nthr) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * nthr + tid;
+        v[u] = i < nvec ? g4[i] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * nthr + tid;
+        if (i < nvec) l4[i] = v[u];
+      }
+    }
+    for (int i = (nvec << 4) / (int)sizeof(T) + tid; i < count * 3; i += nthr) lds[i] = g[i];
+  } else {
+    for (int base = 0; base < count * 3; base += 8 * nthr) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * nthr + tid;
+        v[u] = i < count * 3 ? g[i] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * nthr + tid;
+        if (i < count * 3) lds[i] = v[u];
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -56,7 +110,7 @@ template <typename T, int G, int TS>
 __global__ __launch_bounds__(kQueryThreads) void ball_query_kernel(const T* __restrict__ q, const T* __restrict__ s,
                                                                    int64_t* __restrict__ out, int M, int N, int k,
                                                                    T r2) {
-  __shared__ T tile[TS * 3];
+  __shared__ __align__(16) T tile[TS * 3];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -81,34 +135,50 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_kernel(const T* __re
     const int tcount = min(TS, N - t0);
     __syncthreads();
     stage_supports_aos(s_cloud, t0, tcount, tile);
+    {  // pad the last chunk to 64 supports with points at +inf: their distance is +inf, never below the radius
+      const int padded = (tcount + 63) & ~63;
+      for (int i = tcount * 3 + (int)threadIdx.x; i < padded * 3; i += kQueryThreads) tile[i] = static_cast<T>(INFINITY);
+    }
     __syncthreads();
     bool all_full = true;
 #pragma unroll
     for (int g = 0; g < G; ++g) all_full = all_full && (cnt[g] >= k);
     if (all_full) continue;  // wave-uniform; keep taking part in the barriers
+    // A full (or dead) query compares against -1 so it can never hit again: the common no-hit chunk is then
+    // branch-free (G distance evaluations, G compares, one combined test) and only chunks with a hit pay for slot
+    // assignment and stores.
+    T lim[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) lim[g] = cnt[g] < k ? r2 : static_cast<T>(-1);
     for (int c0 = 0; c0 < tcount; c0 += 64) {
       const int j = c0 + lane;
-      const bool valid = j < tcount;
-      const int jj = valid ? j : 0;
-      const T sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
-      bool any_open = false;
+      const T sx = tile[j * 3 + 0], sy = tile[j * 3 + 1], sz = tile[j * 3 + 2];  // tail lanes read +inf padding
+      unsigned long long m[G];
+      unsigned long long any = 0ull;
+#pragma unroll
+      for (int g = 0; g < G; g += 2) {
+        T d0, d1;
+        sq_dist_pair(qx[g], qy[g], qz[g], qx[g + 1], qy[g + 1], qz[g + 1], sx, sy, sz, d0, d1);
+        m[g] = __ballot(d0 < lim[g]);  // strict, ball_query_cuda.cuh:43
+        m[g + 1] = __ballot(d1 < lim[g + 1]);
+        any |= m[g] | m[g + 1];
+      }
+      if (any == 0ull) continue;
+      bool open = false;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        if (cnt[g] < k) {  // wave-uniform
-          T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
-          bool hit = valid && (d < r2);  // strict, ball_query_cuda.cuh:43
-          unsigned long long m = __ballot(hit);
-          if (m) {
-            int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            int slot = cnt[g] + before;
-            if (hit && slot < k) out[((int64_t)b * M + q_first + g) * k + slot] = (int64_t)(t0 + j);
-            if (first[g] < 0) first[g] = t0 + c0 + (__builtin_ffsll((long long)m) - 1);
-            cnt[g] += __builtin_popcountll(m);
-          }
-          any_open = any_open || (cnt[g] < k);
+        if (m[g]) {  // wave-uniform
+          const bool hit = (m[g] >> lane) & 1ull;
+          const int before = __builtin_popcountll(m[g] & ((1ull << lane) - 1ull));
+          const int slot = cnt[g] + before;
+          if (hit && slot < k) out[((int64_t)b * M + q_first + g) * k + slot] = (int64_t)(t0 + j);
+          if (first[g] < 0) first[g] = t0 + c0 + (__builtin_ffsll((long long)m[g]) - 1);
+          cnt[g] += __builtin_popcountll(m[g]);
+          if (cnt[g] >= k) lim[g] = static_cast<T>(-1);
         }
+        open = open || (cnt[g] < k);
       }
-      if (!any_open) break;
+      if (!open) break;
     }
   }
   // A query with 0 < cnt < k repeats its first hit in the remaining slots (ball_query_cuda.cuh:44-48);
@@ -413,7 +483,7 @@ template <typename T, int R, int QPW, int TS>
 __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __restrict__ q, const T* __restrict__ s,
                                                                    T* __restrict__ out_d, int64_t* __restrict__ out_i,
                                                                    int M, int N, int k) {
-  __shared__ T tile[TS * 3];
+  __shared__ __align__(16) T tile[TS * 3];
   __shared__ HeapSlot<T> heaps[kWavesPerBlock * V3D_KNN_MAX_K];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
