@@ -63,6 +63,45 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // Grid dims y/z are limited to 65535; x to 2^31-1.
 constexpr int kMaxGridYZ = 65535;
 
+
+// XCD-aware workgroup placement.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with a private
+// 4 MiB L2.  All position tiles and channel tiles of one cloud re-read that cloud's source rows and indices, so the
+// launch is a 1-D grid decoded such that every workgroup of a cloud (mode 1, B % 8 == 0) or of a (cloud, channel
+// tile) pair (mode 2) carries the same id % 8: the rows are then fetched from HBM by ONE L2 instead of eight.
+// Placement is a speed matter only; any mapping gives the same result.
+struct GridMap {
+  int X, Y, mode;
+};
+__device__ __forceinline__ void decode_block(const GridMap g, int& bx, int& by, int& bz) {
+  const unsigned id = blockIdx.x;
+  if (g.mode == 0) {
+    bx = id % g.X;
+    by = (id / g.X) % g.Y;
+    bz = id / (g.X * g.Y);
+  } else {
+    const unsigned xcd = id & 7u, slot = id >> 3;
+    if (g.mode == 1) {
+      const unsigned per_b = g.X * g.Y;
+      bz = (slot / per_b) * 8 + xcd;
+      const unsigned rem = slot % per_b;
+      bx = rem % g.X;
+      by = rem / g.X;
+    } else {
+      const unsigned grp = (slot / g.X) * 8 + xcd;
+      bx = slot % g.X;
+      by = grp % g.Y;
+      bz = grp / g.Y;
+    }
+  }
+}
+inline GridMap make_grid_map(int64_t X, int64_t Y, int64_t B) {
+  GridMap g;
+  g.X = (int)X;
+  g.Y = (int)Y;
+  g.mode = (B % 8 == 0) ? 1 : ((B * Y) % 8 == 0 ? 2 : 0);
+  return g;
+}
+
 }  // namespace v3d
 
 #endif

@@ -27,44 +27,6 @@ struct alignas(sizeof(E) * VEC) Pack {
 
 constexpr int kGatherThreads = 256;
 
-// XCD-aware workgroup placement.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with a private
-// 4 MiB L2.  All position tiles and channel tiles of one cloud re-read that cloud's source rows and indices, so the
-// launch is a 1-D grid decoded such that every workgroup of a cloud (mode 1, B % 8 == 0) or of a (cloud, channel
-// tile) pair (mode 2) carries the same id % 8: the rows are then fetched from HBM by ONE L2 instead of eight.
-// Placement is a speed matter only; any mapping gives the same result.
-struct GridMap {
-  int X, Y, mode;
-};
-__device__ __forceinline__ void decode_block(const GridMap g, int& bx, int& by, int& bz) {
-  const unsigned id = blockIdx.x;
-  if (g.mode == 0) {
-    bx = id % g.X;
-    by = (id / g.X) % g.Y;
-    bz = id / (g.X * g.Y);
-  } else {
-    const unsigned xcd = id & 7u, slot = id >> 3;
-    if (g.mode == 1) {
-      const unsigned per_b = g.X * g.Y;
-      bz = (slot / per_b) * 8 + xcd;
-      const unsigned rem = slot % per_b;
-      bx = rem % g.X;
-      by = rem / g.X;
-    } else {
-      const unsigned grp = (slot / g.X) * 8 + xcd;
-      bx = slot % g.X;
-      by = grp % g.Y;
-      bz = grp / g.Y;
-    }
-  }
-}
-static GridMap make_grid_map(int64_t X, int64_t Y, int64_t B) {
-  GridMap g;
-  g.X = (int)X;
-  g.Y = (int)Y;
-  g.mode = (B % 8 == 0) ? 1 : ((B * Y) % 8 == 0 ? 2 : 0);
-  return g;
-}
-
 // Streaming store of one packed vector: the gathered output is written once and never re-read by this kernel, so it
 // is stored non-temporally (V3D_GATHER_NT=0 switches to plain stores; tuning aid).
 template <typename E, int VEC>
@@ -93,6 +55,26 @@ __device__ __forceinline__ int fetch_index(const int64_t* __restrict__ idx, int6
   return (v >= 0 && v < N) ? v : -1;
 }
 
+// VEC consecutive indices of one thread: two int64 per 16-byte load when the tile is interior and aligned.
+template <int VEC>
+__device__ __forceinline__ void fetch_indices(const int64_t* __restrict__ bidx, int64_t p0, int64_t L, int N,
+                                              bool idx_vec, int (&v)[VEC]) {
+  static_assert(VEC % 2 == 0, "VEC must be even");
+  if (idx_vec && p0 + VEC <= L) {
+    const longlong2* src2 = reinterpret_cast<const longlong2*>(bidx + p0);
+#pragma unroll
+    for (int e = 0; e < VEC / 2; ++e) {
+      const longlong2 t = src2[e];
+      const int a = (int)t.x, c = (int)t.y;
+      v[2 * e] = (a >= 0 && a < N) ? a : -1;
+      v[2 * e + 1] = (c >= 0 && c < N) ? c : -1;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = fetch_index(bidx, p0 + e, L, N);
+  }
+}
+
 // LDS path.  NSTAGE = 16-byte vectors each thread moves per source row (0: rows that are not 16-byte
 // tileable are staged element-wise).  Row buffers hold N+1 elements: slot N is a zero that out-of-range
 // indices are redirected to, so the gather loop carries no per-element range check.  Requires 16-byte stores
@@ -112,14 +94,14 @@ __global__ __launch_bounds__(T) void gather_fwd_lds_kernel(
 
   int my[R][VEC];
   const int64_t* bidx = idx + (int64_t)b * L;
+  const bool idx_vec = (reinterpret_cast<uintptr_t>(bidx) & 15) == 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     int64_t p0 = tile0 + ((int64_t)r * T + tid) * VEC;
+    int v[VEC];
+    fetch_indices<VEC>(bidx, p0, L, N, idx_vec, v);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      int v = fetch_index(bidx, p0 + e, L, N);
-      my[r][e] = v < 0 ? N : v;
-    }
+    for (int e = 0; e < VEC; ++e) my[r][e] = v[e] < 0 ? N : v[e];
   }
   if (tid == 0) {
     smem[N] = E(0);
@@ -196,11 +178,11 @@ __global__ __launch_bounds__(kGatherThreads) void gather_fwd_direct_kernel(
   const int64_t tile0 = (int64_t)bx * (kGatherThreads * VEC * R);
   int my[R][VEC];
   const int64_t* bidx = idx + (int64_t)b * L;
+  const bool idx_vec = (reinterpret_cast<uintptr_t>(bidx) & 15) == 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     int64_t p0 = tile0 + ((int64_t)r * kGatherThreads + tid) * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) my[r][e] = fetch_index(bidx, p0 + e, L, N);
+    fetch_indices<VEC>(bidx, p0, L, N, idx_vec, my[r]);
   }
 #pragma unroll 2
   for (int c = c0; c < c1; ++c) {
@@ -255,9 +237,10 @@ static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, i
     T = threads;
     R = (L >= (int64_t)T * VEC * R_BIG) ? R_BIG : R_SMALL;
     xblocks = ceil_div(L, (int64_t)T * VEC * R);
-    // channel tile: as large as possible (index reuse, staging amortisation) while keeping >= ~8192 waves
+    // channel tile: as large as possible (index reuse, staging amortisation) while keeping >= 2 waves per SIMD
+    // (measured on MI355X: re-loading the index tile per channel tile costs more than lower occupancy)
     CT = 16;
-    while (CT > 2 && xblocks * ceil_div(C, CT) * B * (T / 64) < 8192) CT >>= 1;
+    while (CT > 2 && xblocks * ceil_div(C, CT) * B * (T / 64) < 2048) CT >>= 1;
     if (CT > C) CT = C;
   };
   plan(kGatherThreads);
