@@ -307,328 +307,9 @@ static int gather_fwd_dispatch(const char* what, const void* src, const int64_t*
   }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// backward: CSR inversion of the index tensor + per-(b,c,n) ordered segment sums
-// ------------------------------------------------------------------------------------------------------
-struct ScatterWorkspace {
-  int32_t* offsets;   // [B][N+1]  exclusive prefix of per-source counts
-  int32_t* cursor;    // [B][N]    counts, then fill cursors
-  int32_t* unsorted;  // [B][L]    target positions grouped by source, arbitrary order inside a group
-  int32_t* sorted;    // [B][L]    ascending inside every group
-  size_t bytes;
-};
-
-static ScatterWorkspace carve_workspace(void* base, int B, int N, int64_t L) {
-  ScatterWorkspace w;
-  size_t off = 0;
-  auto take = [&](size_t n) {
-    void* p = base ? static_cast<char*>(base) + off : nullptr;
-    off += align_up(n, 256);
-    return static_cast<int32_t*>(p);
-  };
-  w.offsets = take(sizeof(int32_t) * (size_t)B * ((size_t)N + 1));
-  w.cursor = take(sizeof(int32_t) * (size_t)B * (size_t)N);
-  w.unsorted = take(sizeof(int32_t) * (size_t)B * (size_t)L);
-  w.sorted = take(sizeof(int32_t) * (size_t)B * (size_t)L);
-  w.bytes = off;
-  return w;
-}
-
-__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ idx, int32_t* cursor, int N,
-                                                        int64_t L) {
-  const int b = blockIdx.y;
-  const int64_t* bidx = idx + (int64_t)b * L;
-  int32_t* cur = cursor + (int64_t)b * N;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L; p += (int64_t)gridDim.x * blockDim.x) {
-    int key = (int)bidx[p];
-    if (key >= 0 && key < N) atomicAdd(&cur[key], 1);
-  }
-}
-
-// One workgroup per cloud: exclusive scan of the counts, and reset of the cursors for the fill pass.
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* cursor, int32_t* offsets, int N) {
-  __shared__ int wave_tot[16];
-  __shared__ int carry_s;
-  const int b = blockIdx.x;
-  int32_t* cur = cursor + (int64_t)b * N;
-  int32_t* off = offsets + (int64_t)b * (N + 1);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < N; base += 1024) {
-    int i = base + tid;
-    int v = i < N ? cur[i] : 0;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
-    int carry = carry_s;
-    if (i < N) {
-      off[i] = carry + wave_base + incl - v;
-      cur[i] = 0;
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wave_base + incl;
-    __syncthreads();
-  }
-  if (tid == 0) off[N] = carry_s;
-}
-
-__global__ __launch_bounds__(256) void csr_fill_kernel(const int64_t* __restrict__ idx,
-                                                       const int32_t* __restrict__ offsets, int32_t* cursor,
-                                                       int32_t* unsorted, int N, int64_t L) {
-  const int b = blockIdx.y;
-  const int64_t* bidx = idx + (int64_t)b * L;
-  const int32_t* off = offsets + (int64_t)b * (N + 1);
-  int32_t* cur = cursor + (int64_t)b * N;
-  int32_t* uns = unsorted + (int64_t)b * L;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L; p += (int64_t)gridDim.x * blockDim.x) {
-    int key = (int)bidx[p];
-    if (key >= 0 && key < N) {
-      int slot = off[key] + atomicAdd(&cur[key], 1);
-      uns[slot] = (int32_t)p;
-    }
-  }
-}
-
-// Rank sort inside every group: positions are distinct, so rank = number of smaller members.
-__global__ __launch_bounds__(256) void csr_rank_kernel(const int64_t* __restrict__ idx,
-                                                       const int32_t* __restrict__ offsets,
-                                                       const int32_t* __restrict__ unsorted, int32_t* sorted,
-                                                       int N, int64_t L) {
-  const int b = blockIdx.y;
-  const int64_t* bidx = idx + (int64_t)b * L;
-  const int32_t* off = offsets + (int64_t)b * (N + 1);
-  const int32_t* uns = unsorted + (int64_t)b * L;
-  int32_t* srt = sorted + (int64_t)b * L;
-  const int filled = off[N];
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < filled;
-       s += (int64_t)gridDim.x * blockDim.x) {
-    int e = uns[s];
-    int key = (int)bidx[e];
-    int start = off[key], end = off[key + 1];
-    int rank = 0;
-    for (int j = start; j < end; ++j) rank += (uns[j] < e) ? 1 : 0;
-    srt[start + rank] = e;
-  }
-}
-
-// MODE 0: value(t) = gout[row + t]                       (gather / group_gather backward)
-// MODE 1: value(t) = gout[row + t/3] * w[b][t]           (three_interpolate backward, product rounded first)
-template <typename T, int MODE, int CT>
-__global__ __launch_bounds__(256) void segment_sum_kernel(const T* __restrict__ gout, const T* __restrict__ w,
-                                                          const int32_t* __restrict__ offsets,
-                                                          const int32_t* __restrict__ sorted, T* __restrict__ gsrc,
-                                                          int C, int N, int64_t L, int64_t Lrow) {
-  const int b = blockIdx.z;
-  const int c0 = blockIdx.y * CT;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const int32_t* off = offsets + (int64_t)b * (N + 1);
-  const int32_t* srt = sorted + (int64_t)b * L;
-  const T* wb = MODE == 1 ? w + (int64_t)b * L : nullptr;
-  const int start = off[n], end = off[n + 1];
-  T acc[CT];
-#pragma unroll
-  for (int i = 0; i < CT; ++i) acc[i] = T(0);
-  const T* g0 = gout + ((int64_t)b * C + c0) * Lrow;
-  for (int j = start; j < end; ++j) {
-    int t = srt[j];
-    int64_t col = MODE == 1 ? (int64_t)(t / 3) : (int64_t)t;
-    T wt = MODE == 1 ? wb[t] : T(1);
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-      if (c0 + i < C) {
-        T v = g0[(int64_t)i * Lrow + col];
-        if (MODE == 1) v = v * wt;
-        acc[i] = acc[i] + v;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < CT; ++i)
-    if (c0 + i < C) gsrc[((int64_t)b * C + c0 + i) * N + n] = acc[i];
-}
-
-// LDS variant of the ordered segment sum: one workgroup owns CT channels of one cloud and sweeps the target
-// positions in chunks of P; the chunk of grad_out (CT x P) is staged in LDS with coalesced 16-byte loads, then
-// every thread walks the (ascending) target lists of its NPT sources as far as the chunk reaches, adding from LDS.
-// grad_out is read from HBM exactly once; the CSR lists are re-read per channel tile from L2.  Summation order per
-// (b,c,n) is still ascending t, so the result is bit-identical to segment_sum_kernel and to the CPU oracle.
-template <typename T, int MODE, int CT, int NPT, int THREADS>
-__global__ __launch_bounds__(THREADS) void segment_sum_lds_kernel(const T* __restrict__ gout, const T* __restrict__ w,
-                                                                  const int32_t* __restrict__ offsets,
-                                                                  const int32_t* __restrict__ sorted,
-                                                                  T* __restrict__ gsrc, int C, int N, int64_t L,
-                                                                  int64_t Lrow, int P, int vec_ok) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);  // [CT][P]
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int c0 = blockIdx.x * CT;
-  const int32_t* off = offsets + (int64_t)b * (N + 1);
-  const int32_t* srt = sorted + (int64_t)b * L;
-  const T* wb = MODE == 1 ? w + (int64_t)b * L : nullptr;
-  int cur[NPT], end[NPT];
-  T acc[NPT][CT];
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    const int n = j * THREADS + tid;
-    cur[j] = n < N ? off[n] : 0;
-    end[j] = n < N ? off[n + 1] : 0;
-#pragma unroll
-    for (int i = 0; i < CT; ++i) acc[j][i] = T(0);
-  }
-  constexpr int kVec = 16 / sizeof(T);
-  for (int64_t col0 = 0; col0 < Lrow; col0 += P) {
-    const int pc = (int)min((int64_t)P, Lrow - col0);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-      if (c0 + i < C) {
-        const T* row = gout + ((int64_t)b * C + c0 + i) * Lrow + col0;
-        T* dst = tile + i * P;
-        if (vec_ok) {
-          const int nv = pc / kVec;
-          for (int v = tid; v < nv; v += THREADS)
-            reinterpret_cast<uint4*>(dst)[v] = reinterpret_cast<const uint4*>(row)[v];
-          for (int e = nv * kVec + tid; e < pc; e += THREADS) dst[e] = row[e];
-        } else {
-          for (int e = tid; e < pc; e += THREADS) dst[e] = row[e];
-        }
-      }
-    }
-    __syncthreads();
-    const int64_t col_end = col0 + pc;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      while (cur[j] < end[j]) {
-        const int t = srt[cur[j]];
-        const int64_t col = MODE == 1 ? (int64_t)(t / 3) : (int64_t)t;
-        if (col >= col_end) break;
-        const T wt = MODE == 1 ? wb[t] : T(1);
-        const int lc = (int)(col - col0);
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-          T v = tile[i * P + lc];
-          if (MODE == 1) v = v * wt;
-          acc[j][i] = acc[j][i] + v;
-        }
-        ++cur[j];
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    const int n = j * THREADS + tid;
-    if (n < N) {
-#pragma unroll
-      for (int i = 0; i < CT; ++i)
-        if (c0 + i < C) gsrc[((int64_t)b * C + c0 + i) * N + n] = acc[j][i];
-    }
-  }
-}
-
-template <typename T, int MODE>
-static int scatter_backward(const char* what, const T* gout, const int64_t* idx, const T* w, T* gsrc, int B, int C,
-                            int N, int64_t L, void* workspace, size_t workspace_bytes, int device, void* stream_) {
-  V3D_REQUIRE(B >= 0 && C >= 0 && N >= 0 && L >= 0, what, "negative dimension");
-  if (B == 0 || C == 0 || N == 0) return 0;
-  V3D_REQUIRE(gsrc && (L == 0 || (gout && idx)) && (MODE == 0 || L == 0 || w), what, "null pointer");
-  if (B > kMaxGridYZ || L > (int64_t)INT32_MAX) {
-    set_last_error("%s: B <= 65535 and targets per cloud < 2^31 required", what);
-    return V3D_ERR_SIZE_LIMIT;
-  }
-  DeviceGuard guard(device);
-  if (guard.rc) return guard.rc;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (L == 0) {
-    V3D_HIP_TRY(hipMemsetAsync(gsrc, 0, sizeof(T) * (size_t)B * C * N, stream), what);
-    return 0;
-  }
-  const size_t need = carve_workspace(nullptr, B, N, L).bytes;
-  void* base = workspace;
-  bool own = false;
-  if (base == nullptr) {
-    V3D_HIP_TRY(hipMallocAsync(&base, need, stream), what);
-    own = true;
-  } else if (workspace_bytes < need || ((uintptr_t)base & 255) != 0) {
-    set_last_error("%s: workspace needs %zu bytes, 256-B aligned (got %zu)", what, need, workspace_bytes);
-    return V3D_ERR_WORKSPACE;
-  }
-  ScatterWorkspace ws = carve_workspace(base, B, N, L);
-  int rc = 0;
-  do {
-    hipError_t e = hipMemsetAsync(ws.cursor, 0, sizeof(int32_t) * (size_t)B * N, stream);
-    if (e != hipSuccess) {
-      set_last_error("%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
-      rc = (int)e;
-      break;
-    }
-    const unsigned xb = (unsigned)std::min<int64_t>(ceil_div(L, 256), 1024);
-    hipLaunchKernelGGL(csr_count_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.cursor, N, L);
-    hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, stream, ws.cursor, ws.offsets, N);
-    hipLaunchKernelGGL(csr_fill_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.cursor,
-                       ws.unsorted, N, L);
-    hipLaunchKernelGGL(csr_rank_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.unsorted,
-                       ws.sorted, N, L);
-    const int64_t Lrow = MODE == 1 ? L / 3 : L;
-    if (N <= 4096) {
-      constexpr int CT = 4, THREADS = 1024;
-      const int P = (int)std::min<int64_t>(16384 / sizeof(T), align_up((size_t)Lrow, 4));  // CT*P*sizeof(T) <= 64 KiB
-      const int vec_ok = (Lrow % (16 / sizeof(T)) == 0) && ((uintptr_t)gout % 16 == 0);
-      const size_t lds = (size_t)CT * P * sizeof(T);
-      dim3 grid((unsigned)ceil_div(C, CT), (unsigned)B);
-      if (N <= 1024)
-        hipLaunchKernelGGL((segment_sum_lds_kernel<T, MODE, CT, 1, THREADS>), grid, dim3(THREADS), lds, stream, gout,
-                           w, ws.offsets, ws.sorted, gsrc, C, N, L, Lrow, P, vec_ok);
-      else
-        hipLaunchKernelGGL((segment_sum_lds_kernel<T, MODE, CT, 4, THREADS>), grid, dim3(THREADS), lds, stream, gout,
-                           w, ws.offsets, ws.sorted, gsrc, C, N, L, Lrow, P, vec_ok);
-    } else {
-      constexpr int CT = 8;
-      dim3 grid((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, CT), (unsigned)B);
-      hipLaunchKernelGGL((segment_sum_kernel<T, MODE, CT>), grid, dim3(256), 0, stream, gout, w, ws.offsets,
-                         ws.sorted, gsrc, C, N, L, Lrow);
-    }
-    rc = launch_status(what);
-  } while (0);
-  if (own) {
-    hipError_t e = hipFreeAsync(base, stream);
-    if (rc == 0 && e != hipSuccess) {
-      set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
-      rc = (int)e;
-    }
-  }
-  return rc;
-}
-
-// used by interp.hip
-int three_interp_bwd_f32_impl(const float* gout, const int64_t* idx, const float* w, float* gsrc, int B, int C,
-                              int S, int Q, void* ws, size_t wsb, int device, void* stream) {
-  return scatter_backward<float, 1>("three_interpolate_backward", gout, idx, w, gsrc, B, C, S, (int64_t)Q * 3, ws,
-                                    wsb, device, stream);
-}
-int three_interp_bwd_f64_impl(const double* gout, const int64_t* idx, const double* w, double* gsrc, int B, int C,
-                              int S, int Q, void* ws, size_t wsb, int device, void* stream) {
-  return scatter_backward<double, 1>("three_interpolate_backward", gout, idx, w, gsrc, B, C, S, (int64_t)Q * 3, ws,
-                                     wsb, device, stream);
-}
-
 }  // namespace v3d
 
 extern "C" {
-
-size_t v3d_scatter_workspace_bytes(int B, int num_sources, int64_t positions_per_batch) {
-  if (B <= 0 || num_sources < 0 || positions_per_batch < 0) return 0;
-  return v3d::carve_workspace(nullptr, B, num_sources, positions_per_batch).bytes;
-}
 
 int v3d_gather_fwd(const void* sources, const int64_t* indices, void* targets, int B, int C, int N, int M,
                    int elem_bytes, int device, void* stream) {
@@ -641,29 +322,6 @@ int v3d_group_gather_fwd(const void* sources, const int64_t* indices, void* targ
   if (M < 0 || K < 0) return v3d::invalid("group_gather_forward", "negative dimension");
   return v3d::gather_fwd_dispatch("group_gather_forward", sources, indices, targets, B, C, N, (int64_t)M * K,
                                   elem_bytes, device, stream);
-}
-
-int v3d_gather_bwd_f32(const float* g, const int64_t* idx, float* gs, int B, int C, int N, int M, void* ws,
-                       size_t wsb, int device, void* stream) {
-  return v3d::scatter_backward<float, 0>("gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M, ws, wsb,
-                                         device, stream);
-}
-int v3d_gather_bwd_f64(const double* g, const int64_t* idx, double* gs, int B, int C, int N, int M, void* ws,
-                       size_t wsb, int device, void* stream) {
-  return v3d::scatter_backward<double, 0>("gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M, ws, wsb,
-                                          device, stream);
-}
-int v3d_group_gather_bwd_f32(const float* g, const int64_t* idx, float* gs, int B, int C, int N, int M, int K,
-                             void* ws, size_t wsb, int device, void* stream) {
-  if (M < 0 || K < 0) return v3d::invalid("group_gather_backward", "negative dimension");
-  return v3d::scatter_backward<float, 0>("group_gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M * K,
-                                         ws, wsb, device, stream);
-}
-int v3d_group_gather_bwd_f64(const double* g, const int64_t* idx, double* gs, int B, int C, int N, int M, int K,
-                             void* ws, size_t wsb, int device, void* stream) {
-  if (M < 0 || K < 0) return v3d::invalid("group_gather_backward", "negative dimension");
-  return v3d::scatter_backward<double, 0>("group_gather_backward", g, idx, nullptr, gs, B, C, N, (int64_t)M * K,
-                                          ws, wsb, device, stream);
 }
 
 }  // extern "C"
