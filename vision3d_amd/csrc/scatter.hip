@@ -7,23 +7,28 @@
 //     MODE 1: value = grad_out[b,c,t/3] * weight[b,t]           (three_interpolate; product rounded first)
 //
 // grad_out is channel-major (positions contiguous) while the sum runs over positions grouped by source: the
-// transposition goes through LDS.  Per call, once for all channels, the index tensor is inverted into a CSR keyed by
-// (column chunk, source): count -> scan -> fill -> rank-sort (32-bit integer atomics on the small count/cursor arrays
-// only).  The main kernel gives a workgroup CT channels of one cloud; per column chunk it stages the CT x P tile of
-// grad_out with 16-byte loads, the chunk's entry list (16-bit local columns, already in (source, t) order), its
-// weights and its row of offsets in LDS, and every thread then walks the entries of its own sources with LDS
-// latency only, carrying its accumulators across chunks in registers.  One thread sums one (b,c,n) in ascending t: no
-// float atomics, and the result equals the sequential CPU loop bit for bit.
+// transposition goes through LDS, in column chunks of P = 2048.
+//   1. csr_chunk_build_kernel, once per call for all channels: one workgroup inverts one chunk of one cloud entirely
+//      in LDS (histogram, scan, fill, rank sort; LDS integer atomics only) and writes the chunk's entry list (16-bit
+//      local columns in (source, t) order, bit 15 marks the last entry of a source), the weights in the same order,
+//      and a compact list of the non-empty sources ("segments": source | first entry << 16).
+//   2. segment_sum_kernel: a workgroup owns CT channels of one cloud and keeps acc[N][CT] in LDS.  Per chunk it
+//      stages the CT x P tile of grad_out transposed to [column][CT] (one 16-byte LDS read per entry and 4
+//      channels), the entry list and the weights; then ONE THREAD PER SEGMENT reads acc[n], adds its entries in
+//      order and writes acc[n] back: every lane has work, whatever the index distribution.  Chunks are two deep in
+//      flight through two register sets, since one workgroup fills a CU.
+// One thread sums one (b,c,n) in ascending t: no float atomics, and the result equals the sequential CPU loop bit
+// for bit.  Clouds with more than 4096 sources take a generic path (global CSR, thread per source, L2 gathers).
 #include <algorithm>
 
 #include "common.h"
 
 namespace v3d {
 
-constexpr int kChunkCols = 2048;        // columns of grad_out per chunk (MODE 1: three entries per column)
-constexpr int kMaxLdsSources = 4096;    // above this the sources of a cloud do not fit one workgroup's registers
-constexpr int kScatterThreads = 1024;     // CSR build workgroup
-constexpr int kSumThreads = 512;          // summing workgroup: two of them share a CU
+constexpr int kChunkCols = 2048;      // columns of grad_out per chunk (MODE 1: three entries per column)
+constexpr int kMaxLdsSources = 4096;  // acc[N][CT] must fit LDS beside the tile
+constexpr int kScatterThreads = 1024;
+constexpr unsigned kNoSegment = 0xFFFFFFFFu;
 
 template <int MODE>
 struct ChunkGeom {
@@ -31,14 +36,15 @@ struct ChunkGeom {
   static constexpr int EMAX = MODE == 1 ? 3 * P : P;  // entries (target positions) a chunk can hold
 };
 
-static int offrow_stride(int N) { return (int)align_up((size_t)N + 1, 8); }  // uint16 elements, 16-byte rows
+// segments a chunk can hold: one per source that has an entry in it (multiple of 4)
+static int seg_stride(int N, int emax) { return (int)align_up((size_t)std::min(N, emax), 4); }
 
 // Two workspace layouts share one allocation (sized for the larger, so that v3d_scatter_workspace_bytes needs
 // neither mode nor dtype):
-//   chunked (N <= kMaxLdsSources): offrow u16 [B][nchunks][stride(N)] | ent u16 [B][nchunks][EMAX] | wsorted T [..]
+//   chunked (N <= kMaxLdsSources): seg u32 [B][nchunks][seg_stride] | ent u16 [B][nchunks][EMAX] | wsorted T [..]
 //   generic                      : offsets i32 [B][N+1] | cursor i32 [B][N] | unsorted i32 [B][L] | sorted i32 [B][L]
 struct ScatterWorkspace {
-  uint16_t* offrow;
+  uint32_t* seg;
   uint16_t* ent;
   void* wsorted;
   int32_t* offsets;
@@ -59,7 +65,7 @@ static ScatterWorkspace carve_workspace(void* base, int B, int N, int64_t L) {
   if (N <= kMaxLdsSources) {
     const size_t nch = (size_t)std::max<int64_t>(1, ceil_div(L, kChunkCols));  // MODE 0 has the most chunks
     const size_t emax_total = (size_t)L + 3 * kChunkCols;                       // nchunks*EMAX <= L + EMAX, any mode
-    w.offrow = static_cast<uint16_t*>(take(sizeof(uint16_t) * (size_t)B * nch * offrow_stride(N)));
+    w.seg = static_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)B * nch * seg_stride(N, 3 * kChunkCols)));
     w.ent = static_cast<uint16_t*>(take(sizeof(uint16_t) * (size_t)B * emax_total));
     w.wsorted = take(sizeof(double) * (size_t)B * emax_total);
   } else {
@@ -73,13 +79,13 @@ static ScatterWorkspace carve_workspace(void* base, int B, int N, int64_t L) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// chunked path: one workgroup inverts one column chunk of one cloud entirely in LDS (no global atomics)
+// chunked path
 // ------------------------------------------------------------------------------------------------------
 // LDS: offs i32 [N+1] | cursor i32 [N] | srcl u16 [EMAX] | ul u16 [EMAX]
 template <typename T, int MODE>
 __global__ __launch_bounds__(kScatterThreads) void csr_chunk_build_kernel(
-    const int64_t* __restrict__ idx, const T* __restrict__ w, uint16_t* __restrict__ offrow_g,
-    uint16_t* __restrict__ ent_g, T* __restrict__ wsorted_g, int N, int64_t L, int nchunks, int ostride) {
+    const int64_t* __restrict__ idx, const T* __restrict__ w, uint32_t* __restrict__ seg_g,
+    uint16_t* __restrict__ ent_g, T* __restrict__ wsorted_g, int N, int64_t L, int nchunks, int segs) {
   constexpr int EMAX = ChunkGeom<MODE>::EMAX;
   constexpr int kItems = kMaxLdsSources / kScatterThreads;  // scan items per thread
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -102,13 +108,15 @@ __global__ __launch_bounds__(kScatterThreads) void csr_chunk_build_kernel(
     if (ok) atomicAdd(&offs[src], 1);
   }
   __syncthreads();
-  // exclusive scan of the N counts, kItems consecutive sources per thread
+  // One exclusive scan for two things: entries before source n (low 16 bits; a chunk holds < 2^16 entries) and
+  // non-empty sources before n (high bits).  kItems consecutive sources per thread.
   int v[kItems];
   int sum = 0;
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int n = tid * kItems + i;
-    v[i] = n < N ? offs[n] : 0;
+    const int c = n < N ? offs[n] : 0;
+    v[i] = c + (c > 0 ? (1 << 16) : 0);
     sum += v[i];
   }
   int incl = sum;
@@ -121,29 +129,30 @@ __global__ __launch_bounds__(kScatterThreads) void csr_chunk_build_kernel(
   __syncthreads();
   int run = incl - sum;
   for (int q = 0; q < wave; ++q) run += wave_tot[q];
-  uint16_t* orow = offrow_g + ((int64_t)b * nchunks + k) * ostride;
+  uint32_t* sg = seg_g + ((int64_t)b * nchunks + k) * segs;
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int n = tid * kItems + i;
     if (n < N) {
-      offs[n] = run;
+      const int first = run & 0xFFFF;
+      offs[n] = first;
       cursor[n] = 0;
-      orow[n] = (uint16_t)run;
+      if (v[i] != 0) sg[run >> 16] = (uint32_t)n | ((uint32_t)first << 16);
     }
     run += v[i];
   }
-  if (tid == kScatterThreads - 1) {
-    offs[N] = run;  // entries in this chunk
-    orow[N] = (uint16_t)run;
-  }
+  if (tid == kScatterThreads - 1) offs[N] = run;  // entries | segments << 16 of this chunk
   __syncthreads();
+  const int total = offs[N] & 0xFFFF, nseg = offs[N] >> 16;
+  for (int i = nseg + tid; i < segs; i += kScatterThreads) sg[i] = kNoSegment;
+  __syncthreads();
+  if (tid == 0) offs[N] = total;  // end of the last source's entries for the rank pass
   for (int e = tid; e < ne; e += kScatterThreads) {
     const int src = srcl[e];
     if (src != 0xFFFF) ul[offs[src] + atomicAdd(&cursor[src], 1)] = (uint16_t)e;
   }
   __syncthreads();
   // rank sort inside every group (local positions are distinct: rank = number of smaller members)
-  const int total = offs[N];
   uint16_t* eg = ent_g + ((int64_t)b * nchunks + k) * EMAX;
   T* wg = MODE == 1 ? wsorted_g + ((int64_t)b * nchunks + k) * EMAX : nullptr;
   for (int s = tid; s < total; s += kScatterThreads) {
@@ -152,216 +161,203 @@ __global__ __launch_bounds__(kScatterThreads) void csr_chunk_build_kernel(
     const int start = offs[src], end = offs[src + 1];
     int rank = 0;
     for (int j = start; j < end; ++j) rank += (ul[j] < e) ? 1 : 0;
-    eg[start + rank] = (uint16_t)(MODE == 1 ? e / 3 : e);
+    const int col = MODE == 1 ? e / 3 : e;
+    eg[start + rank] = (uint16_t)(col | (start + rank == end - 1 ? 0x8000 : 0));
     if (MODE == 1) wg[start + rank] = w[(int64_t)b * L + t0 + e];
   }
 }
 
-// Summing kernel of the chunked path, see the file header.  LDS: tile[CT][P] | wl[EMAX] (MODE 1) | ent[EMAX] |
-// offl[stride(N)].  NPT sources per thread (source n = j*TH + tid).  The next chunk's 16-byte loads are issued
-// before the current chunk is summed and land in LDS after it.
-template <typename T, int MODE, int CT, int NPT, int TH>
-__global__ __launch_bounds__(TH, 4) void segment_sum_chunked_kernel(
-    const T* __restrict__ gout, const uint16_t* __restrict__ offrow_g, const uint16_t* __restrict__ ent_g,
-    const T* __restrict__ wsorted_g, T* __restrict__ gsrc, int C, int N, int64_t Lrow, int nchunks, int ostride,
-    int vec_ok, GridMap gm) {
+// Registers that hold one chunk on its way from global memory to LDS.  Every thread issues the same number of
+// loads for every chunk (addresses are clamped, never predicated), so that the compiler can wait for the older of
+// the two register sets with a counted vmcnt while the younger set's loads stay in flight.
+template <typename T, int MODE, int CT>
+struct ChunkRegs {
+  static constexpr int kVec = 16 / sizeof(T);
+  static constexpr int kGroups = ChunkGeom<MODE>::P / kVec;            // 16-byte column groups per grad_out row
+  static constexpr int kRows = CT * kGroups / kScatterThreads;         // rows (channels) a thread loads
+  static constexpr int kEntVecs = ChunkGeom<MODE>::EMAX * 2 / 16;
+  static constexpr int kEntV = (kEntVecs + kScatterThreads - 1) / kScatterThreads;
+  static constexpr int kWVecs = ChunkGeom<MODE>::EMAX * (int)sizeof(T) / 16;
+  static constexpr int kWV = MODE == 1 ? (kWVecs + kScatterThreads - 1) / kScatterThreads : 1;
+  static constexpr int kSeg = MODE == 1 ? 4 : 2;  // segment slots per thread: min(N, EMAX) / 1024
+  static_assert(kRows >= 1 && CT * kGroups % kScatterThreads == 0, "tile must split evenly over the workgroup");
+  uint4 t[kRows];
+  uint4 e[kEntV];
+  uint4 w[kWV];
+  unsigned s[kSeg];
+};
+
+// LDS: acc[N][CT] | tile[P][CT] | wl[EMAX] (MODE 1) | ent[EMAX] (+ pad).  CT * sizeof(T) is 16 or 32 bytes.
+// A thread loads one 16-byte column group (kVec columns) of kRows channels and writes it transposed, kRows
+// channels of one column at a time.
+template <typename T, int MODE, int CT, bool VEC_OK>
+__global__ __launch_bounds__(kScatterThreads) void segment_sum_kernel_lds(
+    const T* __restrict__ gout, const uint32_t* __restrict__ seg_g, const uint16_t* __restrict__ ent_g,
+    const T* __restrict__ wsorted_g, T* __restrict__ gsrc, int C, int N, int64_t Lrow, int nchunks, int segs,
+    GridMap gm) {
+  using Regs = ChunkRegs<T, MODE, CT>;
   constexpr int P = ChunkGeom<MODE>::P;
   constexpr int EMAX = ChunkGeom<MODE>::EMAX;
-  constexpr int kVec = 16 / sizeof(T);
-  constexpr int kRowV = P / kVec;                                  // 16-byte vectors per tile row
-  constexpr int kTileV = CT * kRowV / TH;                          // per thread
-  constexpr int kEntV = (EMAX * 2 / 16 + TH - 1) / TH;
-  constexpr int kWV = MODE == 1 ? (EMAX * (int)sizeof(T) / 16 + TH - 1) / TH : 1;
-  constexpr int kOffV = ((kMaxLdsSources + 8) / 8 + TH - 1) / TH;  // offset row: up to 4104 uint16
-  static_assert(CT * kRowV % TH == 0, "tile must split evenly over the workgroup");
+  constexpr int TH = kScatterThreads;
+  constexpr int kVec = Regs::kVec;
+  constexpr int kGroups = Regs::kGroups;
+  constexpr int kRows = Regs::kRows;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);
-  T* wl = tile + CT * P;
+  T* acc = reinterpret_cast<T*>(smem_raw);
+  T* tile = acc + (size_t)N * CT;
+  T* wl = tile + P * CT;
   uint16_t* ent = reinterpret_cast<uint16_t*>(wl + (MODE == 1 ? EMAX : 0));
-  uint16_t* offl = ent + EMAX;
   const int tid = threadIdx.x;
   int bx, by, b;
   decode_block(gm, bx, by, b);
   const int c0 = bx * CT;
-  const int offv = ostride / 8;  // 16-byte vectors per offset row
-  T acc[NPT][CT];
-#pragma unroll
-  for (int j = 0; j < NPT; ++j)
-#pragma unroll
-    for (int i = 0; i < CT; ++i) acc[j][i] = T(0);
+  for (int i = tid; i < N * CT; i += TH) acc[i] = T(0);
 
-  uint4 rt[kTileV], re[kEntV], rw[kWV], ro[kOffV];
-  // issue the loads of chunk k into registers
-#define V3D_LOAD_CHUNK(k)                                                                                      \
-  do {                                                                                                         \
-    const int64_t col0_ = (int64_t)(k) * P;                                                                    \
-    const int pcv_ = (int)(min((int64_t)P, Lrow - col0_) / kVec);                                              \
-    const int64_t chunk_ = (int64_t)b * nchunks + (k);                                                         \
-    _Pragma("unroll") for (int i = 0; i < kTileV; ++i) {                                                       \
-      const int v = i * TH + tid, row = v / kRowV, within = v % kRowV;                                         \
-      const bool ok = (c0 + row < C) && within < pcv_;                                                         \
-      const uint4* src = reinterpret_cast<const uint4*>(gout + ((int64_t)b * C + (ok ? c0 + row : 0)) * Lrow + \
-                                                         col0_);                                               \
-      rt[i] = ok ? src[within] : make_uint4(0, 0, 0, 0);                                                       \
-    }                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < kEntV; ++i) {                                                        \
-      const int v = i * TH + tid;                                                                              \
-      re[i] = v < EMAX * 2 / 16 ? reinterpret_cast<const uint4*>(ent_g + chunk_ * EMAX)[v]                     \
-                                : make_uint4(0, 0, 0, 0);                                                      \
-    }                                                                                                          \
-    if (MODE == 1) {                                                                                           \
-      _Pragma("unroll") for (int i = 0; i < kWV; ++i) {                                                        \
-        const int v = i * TH + tid;                                                                            \
-        rw[i] = v < EMAX * (int)sizeof(T) / 16 ? reinterpret_cast<const uint4*>(wsorted_g + chunk_ * EMAX)[v]  \
-                                                : make_uint4(0, 0, 0, 0);                                      \
-      }                                                                                                        \
-    }                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < kOffV; ++i) {                                                        \
-      const int v = i * TH + tid;                                                                              \
-      ro[i] = v < offv ? reinterpret_cast<const uint4*>(offrow_g + chunk_ * ostride)[v] : make_uint4(0, 0, 0, 0); \
-    }                                                                                                          \
+  const int grp = tid % kGroups, part = tid / kGroups;  // this thread's tile piece: rows part*kRows .. +kRows-1
+
+#define V3D_LOAD_CHUNK(r, kk)                                                                                   \
+  do {                                                                                                          \
+    const int k_ = min((kk), nchunks - 1);                                                                      \
+    const int64_t chunk_ = (int64_t)b * nchunks + k_;                                                           \
+    const int64_t col_ = (int64_t)k_ * P + (int64_t)grp * kVec;                                                 \
+    _Pragma("unroll") for (int i = 0; i < kRows; ++i) {                                                         \
+      const int c = c0 + part * kRows + i;                                                                      \
+      const T* src = gout + ((int64_t)b * C + min(c, C - 1)) * Lrow;                                            \
+      uint4 v; /* columns past the row end and channels past C are never referenced / written: clamp only */    \
+      if (VEC_OK) {                                                                                             \
+        v = *reinterpret_cast<const uint4*>(src + (col_ < Lrow ? col_ : 0));                                    \
+      } else {                                                                                                  \
+        T tmp[kVec];                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < kVec; ++e) tmp[e] = src[col_ + e < Lrow ? col_ + e : 0];          \
+        v = *reinterpret_cast<const uint4*>(tmp);                                                               \
+      }                                                                                                         \
+      (r).t[i] = v;                                                                                             \
+    }                                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < Regs::kEntV; ++i)                                                     \
+      (r).e[i] = reinterpret_cast<const uint4*>(ent_g + chunk_ * EMAX)[min(i * TH + tid, Regs::kEntVecs - 1)];  \
+    if (MODE == 1) {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < Regs::kWV; ++i)                                                     \
+        (r).w[i] = reinterpret_cast<const uint4*>(wsorted_g + chunk_ * EMAX)[min(i * TH + tid, Regs::kWVecs - 1)]; \
+    }                                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < Regs::kSeg; ++i) {                                                    \
+      const int v = i * TH + tid;                                                                               \
+      (r).s[i] = seg_g[chunk_ * segs + min(v, segs - 1)];                                                       \
+    }                                                                                                           \
   } while (0)
 
-  if (vec_ok) V3D_LOAD_CHUNK(0);
-  for (int k = 0; k < nchunks; ++k) {
-    __syncthreads();  // the previous chunk has been consumed
-    if (vec_ok) {
+#define V3D_STORE_CHUNK(r)                                                                                      \
+  do {                                                                                                          \
+    /* (r).t[i] holds kVec columns of channel part*kRows+i: write kRows channels of one column together */      \
+    _Pragma("unroll") for (int e = 0; e < kVec; ++e) {                                                          \
+      T piece[kRows];                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < kRows; ++i) piece[i] = reinterpret_cast<const T*>(&(r).t[i])[e];    \
+      T* dst = tile + (size_t)(grp * kVec + e) * CT + part * kRows;                                             \
+      _Pragma("unroll") for (int i = 0; i < kRows; ++i) dst[i] = piece[i];                                      \
+    }                                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < Regs::kEntV; ++i) {                                                   \
+      const int v = i * TH + tid;                                                                               \
+      if (v < Regs::kEntVecs) reinterpret_cast<uint4*>(ent)[v] = (r).e[i];                                      \
+    }                                                                                                           \
+    if (MODE == 1) {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < Regs::kWV; ++i) {                                                   \
+        const int v = i * TH + tid;                                                                             \
+        if (v < Regs::kWVecs) reinterpret_cast<uint4*>(wl)[v] = (r).w[i];                                       \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+
+  // one thread per segment: acc[n] += its entries, in order; the next entry is fetched while this one's tile
+  // values are on their way
+#define V3D_SUM_CHUNK(segv)                                                                                     \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < Regs::kSeg; ++i) {                                                    \
+      const unsigned sv = (segv)[i];                                                                            \
+      if (sv != kNoSegment) {                                                                                   \
+        const int n = (int)(sv & 0xFFFFu);                                                                      \
+        int q = (int)(sv >> 16);                                                                                \
+        unsigned en = ent[q];                                                                                   \
+        T wt = MODE == 1 ? wl[q] : T(1);                                                                        \
+        T a[CT];                                                                                                \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c) a[c] = acc[(size_t)n * CT + c];                          \
+        bool last;                                                                                              \
+        do {                                                                                                    \
+          const T* tv = tile + (size_t)(en & 0x7FFFu) * CT;                                                     \
+          T x[CT];                                                                                              \
+          _Pragma("unroll") for (int c = 0; c < CT; ++c) x[c] = tv[c];                                          \
+          last = (en & 0x8000u) != 0;                                                                           \
+          const T wcur = wt;                                                                                    \
+          ++q;                                                                                                  \
+          en = ent[q]; /* one past the chunk's last entry at most: the LDS allocation is padded */              \
+          if (MODE == 1) wt = wl[min(q, EMAX - 1)];                                                             \
+          _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                                      \
+            T y = x[c];                                                                                         \
+            if (MODE == 1) y = y * wcur;                                                                        \
+            a[c] = a[c] + y;                                                                                    \
+          }                                                                                                     \
+        } while (!last && q < EMAX); /* the bound only matters if the lists were corrupted */                   \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c) acc[(size_t)n * CT + c] = a[c];                          \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+
+  // Two register sets, chunks k+2 and k+3 in flight while k and k+1 are summed.  The loop starts two chunks early
+  // (k = -2 only loads) so that each set is defined at ONE place: with a peeled prologue the register allocator
+  // joins the two definitions through copies at the loop latch, and a copy waits for the load it copies.
+  Regs ra, rb;
+  for (int k = -2; k < nchunks; k += 2) {  // an odd tail runs one empty half (no segments)
+    unsigned segv[Regs::kSeg];
+    if (k >= 0) {
+      __syncthreads();  // chunk k-1 consumed (first pass: acc zeroed)
+      V3D_STORE_CHUNK(ra);
 #pragma unroll
-      for (int i = 0; i < kTileV; ++i) reinterpret_cast<uint4*>(tile)[i * TH + tid] = rt[i];
-#pragma unroll
-      for (int i = 0; i < kEntV; ++i) {
-        const int v = i * TH + tid;
-        if (v < EMAX * 2 / 16) reinterpret_cast<uint4*>(ent)[v] = re[i];
-      }
-      if (MODE == 1) {
-#pragma unroll
-        for (int i = 0; i < kWV; ++i) {
-          const int v = i * TH + tid;
-          if (v < EMAX * (int)sizeof(T) / 16) reinterpret_cast<uint4*>(wl)[v] = rw[i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < kOffV; ++i) {
-        const int v = i * TH + tid;
-        if (v < offv) reinterpret_cast<uint4*>(offl)[v] = ro[i];
-      }
-    } else {  // rows that are not 16-byte tileable: element-wise staging, no prefetch
-      const int64_t col0 = (int64_t)k * P;
-      const int pc = (int)min((int64_t)P, Lrow - col0);
-      const int64_t chunk = (int64_t)b * nchunks + k;
-#pragma unroll
-      for (int i = 0; i < CT; ++i) {
-        if (c0 + i < C) {
-          const T* row = gout + ((int64_t)b * C + c0 + i) * Lrow + col0;
-          for (int e = tid; e < pc; e += TH) tile[i * P + e] = row[e];
-        }
-      }
-      for (int e = tid; e < EMAX; e += TH) ent[e] = ent_g[chunk * EMAX + e];
-      if (MODE == 1)
-        for (int e = tid; e < EMAX; e += TH) wl[e] = wsorted_g[chunk * EMAX + e];
-      for (int n = tid; n <= N; n += TH) offl[n] = offrow_g[chunk * ostride + n];
+      for (int i = 0; i < Regs::kSeg; ++i) segv[i] = (i * TH + tid < segs) ? ra.s[i] : kNoSegment;
+      __syncthreads();
     }
-    __syncthreads();
-    if (vec_ok && k + 1 < nchunks) V3D_LOAD_CHUNK(k + 1);
-    // Round-robin over the thread's NPT sources: round r adds entry r of every source that still has one, so the
-    // LDS reads of different sources are independent and in flight together (a source-by-source walk is a chain of
-    // dependent LDS latencies: offsets -> entry -> tile value).  The next round's entries are fetched a round ahead.
-    // fl[j] = first entry | (number of entries << 16) of source j in this chunk
-    unsigned fl[NPT];
-    int lcn[NPT];
-    T wn[NPT];
-    int maxlen = 0;
+    V3D_LOAD_CHUNK(ra, k + 2);
+    if (k >= 0) {
+      V3D_SUM_CHUNK(segv);
+      __syncthreads();
+      V3D_STORE_CHUNK(rb);
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      const int n = j * TH + tid;
-      fl[j] = 0;
-      if (n < N) {
-        const unsigned f = offl[n], e = offl[n + 1];
-        fl[j] = f | ((e - f) << 16);
-      }
-      maxlen = max(maxlen, (int)(fl[j] >> 16));
+      for (int i = 0; i < Regs::kSeg; ++i)
+        segv[i] = (i * TH + tid < segs && k + 1 < nchunks) ? rb.s[i] : kNoSegment;
+      __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      lcn[j] = 0;
-      wn[j] = T(1);
-      if ((fl[j] >> 16) > 0) {
-        lcn[j] = ent[fl[j] & 0xFFFFu];
-        if (MODE == 1) wn[j] = wl[fl[j] & 0xFFFFu];
-      }
-    }
-    for (int r = 0; r < maxlen; ++r) {
-      constexpr int G = NPT < 4 ? NPT : (NPT > 4 ? 2 : 4);  // sources whose tile values are in flight together
-#pragma unroll
-      for (int g = 0; g < NPT; g += G) {
-        T v[G][CT];
-        T wt[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const int cnt = (int)(fl[g + j] >> 16);
-          wt[j] = wn[g + j];
-          if (r < cnt) {
-            const int lc = lcn[g + j];
-#pragma unroll
-            for (int i = 0; i < CT; ++i) v[j][i] = tile[i * P + lc];
-          }
-          if (r + 1 < cnt) {
-            const int q = (int)(fl[g + j] & 0xFFFFu) + r + 1;
-            lcn[g + j] = ent[q];
-            if (MODE == 1) wn[g + j] = wl[q];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          if (r < (int)(fl[g + j] >> 16)) {
-#pragma unroll
-            for (int i = 0; i < CT; ++i) {
-              T x = v[j][i];
-              if (MODE == 1) x = x * wt[j];
-              acc[g + j][i] = acc[g + j][i] + x;
-            }
-          }
-        }
-      }
-    }
+    V3D_LOAD_CHUNK(rb, k + 3);
+    if (k >= 0) V3D_SUM_CHUNK(segv);
   }
 #undef V3D_LOAD_CHUNK
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    const int n = j * TH + tid;
-    if (n < N) {
-#pragma unroll
-      for (int i = 0; i < CT; ++i)
-        if (c0 + i < C) gsrc[((int64_t)b * C + c0 + i) * N + n] = acc[j][i];
-    }
+#undef V3D_STORE_CHUNK
+#undef V3D_SUM_CHUNK
+  __syncthreads();
+  for (int i = tid; i < N * CT; i += TH) {
+    const int c = i / N, n = i - c * N;  // consecutive threads -> consecutive n of one channel: coalesced stores
+    if (c0 + c < C) gsrc[((int64_t)b * C + c0 + c) * N + n] = acc[(size_t)n * CT + c];
   }
 }
 
-template <typename T, int MODE, int CT, int NPT, int TH>
+template <typename T, int MODE, int CT>
 static int launch_chunked(const char* what, const T* gout, const ScatterWorkspace& ws, T* gsrc, int B, int C, int N,
                           int64_t Lrow, int nchunks, hipStream_t stream) {
   constexpr int P = ChunkGeom<MODE>::P;
   constexpr int EMAX = ChunkGeom<MODE>::EMAX;
-  const int ostride = offrow_stride(N);
-  const size_t lds = sizeof(T) * CT * P + (MODE == 1 ? sizeof(T) * EMAX : 0) + sizeof(uint16_t) * EMAX +
-                     sizeof(uint16_t) * (size_t)ostride;
-  auto kernel = segment_sum_chunked_kernel<T, MODE, CT, NPT, TH>;
-  static bool attr_set[64] = {};  // per device: the LDS request exceeds the 64 KiB default for some instantiations
+  const size_t lds =
+      sizeof(T) * CT * ((size_t)N + P) + (MODE == 1 ? sizeof(T) * EMAX : 0) + sizeof(uint16_t) * EMAX + 16;
+  const bool vec_ok = (Lrow % (16 / sizeof(T)) == 0) && ((uintptr_t)gout % 16 == 0);
+  auto kernel = vec_ok ? segment_sum_kernel_lds<T, MODE, CT, true> : segment_sum_kernel_lds<T, MODE, CT, false>;
+  static bool attr_set[64][2] = {};  // per device and variant: the LDS request exceeds the 64 KiB default
   int dev = 0;
   V3D_HIP_TRY(hipGetDevice(&dev), what);
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    constexpr size_t kLdsMax = sizeof(T) * CT * P + sizeof(T) * 3 * P + sizeof(uint16_t) * 3 * P +
-                               sizeof(uint16_t) * (kMaxLdsSources + 8);
+  if (dev < 0 || dev >= 64 || !attr_set[dev][vec_ok]) {
     V3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                 what);
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    if (dev >= 0 && dev < 64) attr_set[dev][vec_ok] = true;
   }
-  const int vec_ok = (Lrow % (16 / sizeof(T)) == 0) && ((uintptr_t)gout % 16 == 0);
   const int64_t ctiles = ceil_div(C, CT);
   const GridMap gm = make_grid_map(ctiles, 1, B);
-  hipLaunchKernelGGL(kernel, dim3((unsigned)(ctiles * B)), dim3(TH), lds, stream, gout, ws.offrow,
-                     ws.ent, static_cast<const T*>(ws.wsorted), gsrc, C, N, Lrow, nchunks, ostride, vec_ok, gm);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(ctiles * B)), dim3(kScatterThreads), lds, stream, gout, ws.seg, ws.ent,
+                     static_cast<const T*>(ws.wsorted), gsrc, C, N, Lrow, nchunks, seg_stride(N, EMAX), gm);
   return 0;
 }
 
@@ -535,19 +531,20 @@ int scatter_backward(const char* what, const T* gout, const int64_t* idx, const 
   do {
     if (chunked) {
       constexpr int EMAX = ChunkGeom<MODE>::EMAX;
-      const int ostride = offrow_stride(N);
       const size_t lds = sizeof(int) * (2 * (size_t)N + 1) + 2 * sizeof(uint16_t) * EMAX;
       hipLaunchKernelGGL((csr_chunk_build_kernel<T, MODE>), dim3((unsigned)nchunks, (unsigned)B),
-                         dim3(kScatterThreads), lds, stream, idx, w, ws.offrow, ws.ent, static_cast<T*>(ws.wsorted), N,
-                         L, nchunks, ostride);
-      constexpr int CT = sizeof(T) == 4 ? 4 : 2;  // 32 KiB tile
-      // two 512-thread workgroups per CU while a thread can hold its sources' accumulators; beyond that one
-      // 1024-thread workgroup (NPT = 8 at 512 threads spills)
-      if (N <= 2 * kSumThreads)
-        rc = launch_chunked<T, MODE, CT, 2, kSumThreads>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
-      else
-        rc = launch_chunked<T, MODE, CT, kMaxLdsSources / 1024, 1024>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks,
-                                                                     stream);
+                         dim3(kScatterThreads), lds, stream, idx, w, ws.seg, ws.ent, static_cast<T*>(ws.wsorted), N, L,
+                         nchunks, seg_stride(N, EMAX));
+      // acc[N][CT] + tile[P][CT] + lists must fit 160 KiB: 32-byte channel vectors up to 1024 sources, else 16-byte
+      constexpr int kQuad = 16 / sizeof(T);
+      bool wide = false;
+      if constexpr (sizeof(T) == 4) {
+        if (N <= 1024) {
+          wide = true;
+          rc = launch_chunked<T, MODE, 8>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
+        }
+      }
+      if (!wide) rc = launch_chunked<T, MODE, kQuad>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
       if (rc != 0) break;
     } else {
       hipError_t e = hipMemsetAsync(ws.cursor, 0, sizeof(int32_t) * (size_t)B * N, stream);
