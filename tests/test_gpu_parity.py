@@ -288,9 +288,12 @@ def test_group_gather_forward_config_shapes(ext, oracle_mod):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_gather_backward_bit_exact(ext, oracle_mod, dtype):
     rng = np.random.default_rng(23)
-    for (b, c, n, m, k) in ((2, 3, 17, 9, 4), (2, 13, 1024, 256, 16), (1, 9, 50, 700, 3), (2, 8, 3000, 100, 2)):
+    # chunked LDS path with 1..16 column chunks, both channel-tile widths (n <= 1024 / n <= 4096), partial channel
+    # tiles, odd row lengths (element-wise staging), and the generic path (n > 4096)
+    for (b, c, n, m, k) in ((2, 3, 17, 9, 4), (2, 13, 1024, 256, 16), (1, 9, 50, 700, 3), (2, 8, 3000, 100, 2),
+                            (3, 10, 4096, 1024, 32), (2, 6, 5000, 300, 7), (1, 5, 4097, 33, 3)):
         idx = rng.integers(0, n, (b, m, k))
-        idx[:, : m // 3] = 0  # a heavy group (ball-query padding pattern)
+        idx[:, : m // 3] = 0  # a heavy group (ball-query padding pattern): one source spanning several chunks
         g = rng.standard_normal((b, c, m, k)).astype(dtype)
         want = oracle_mod.group_gather_backward(g, idx, n)
         out = torch.full((b, c, n), 7.0, dtype=T(g).dtype, device=DEV)  # must be fully overwritten
@@ -321,6 +324,25 @@ def test_three_interpolate(ext, oracle_mod, dtype):
         outb = torch.full((b, c, s), 3.0, dtype=T(src).dtype, device=DEV)
         ext.three_interpolate_backward(T(g), T(idx), T(w), outb, s)
         assert np.array_equal(N_(outb), wantb), (dtype, s, q)
+
+
+def test_backward_single_source_and_full_c2_interp(ext, oracle_mod):
+    """Adversarial index tensors (every target on one source: one segment per chunk, carried across chunks) and the
+    C2 three_interpolate backward at full size against the oracle."""
+    rng = np.random.default_rng(25)
+    b, c, n, m, k = 2, 5, 300, 700, 9
+    idx = np.full((b, m, k), 123, dtype=np.int64)
+    g = rng.standard_normal((b, c, m, k)).astype(np.float32)
+    out = torch.empty((b, c, n), device=DEV)
+    ext.group_gather_backward(T(g), T(idx), out, n)
+    assert np.array_equal(N_(out), oracle_mod.group_gather_backward(g, idx, n))
+    b, c, s, q = 32, 128, 1024, 4096
+    idx = rng.integers(0, s, (b, q, 3))
+    w = rng.random((b, q, 3)).astype(np.float32)
+    g = rng.standard_normal((b, c, q)).astype(np.float32)
+    outb = torch.empty((b, c, s), device=DEV)
+    ext.three_interpolate_backward(T(g), T(idx), T(w), outb, s)
+    assert np.array_equal(N_(outb), oracle_mod.three_interpolate_backward(g, idx, w, s))
 
 
 def test_backward_is_linear_and_reproducible(ext):
