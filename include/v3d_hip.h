@@ -155,6 +155,20 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
 int v3d_topk_merge_f32(const float* parts_dist, const int64_t* parts_idx, float* out_dist, int64_t* out_idx,
                        int G, int64_t rows, int k, int device, void* stream);
 
+/* ---- "next" rows: pack-mode neighbourhood construction of the KPConv / GeoTransformer pyramid ----
+ * Pack mode = variable-length clouds concatenated: points (total,3) fp32 + lengths (B,) int64, all in device memory.
+ *
+ * Radius search, replaces vision3d/ops/radius_search.py:44-71 (pack -> padded batch -> pykeops kNN -> mask -> pack):
+ * neighbor_indices (total_q, neighbor_limit) = the supports of the query's own cloud with NOT(sqrt(d2) > radius),
+ * ascending by (d2, index), first `neighbor_limit` (<= 128), padded with total_s.  The lengths must sum to the totals.
+ * No host synchronisation.  Scratch: v3d_radius_search_workspace_bytes(B, total_s) bytes or NULL (stream-ordered
+ * allocation). */
+size_t v3d_radius_search_workspace_bytes(int B, int64_t total_s);
+int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths,
+                               const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q,
+                               int64_t total_s, float radius, int neighbor_limit, void* workspace,
+                               size_t workspace_bytes, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,3 +202,29 @@ def knn_feat(x, y, k):
     idx = np.zeros((xb.shape[0], N, k), dtype=np.int64)
     lib().v3d_oracle_knn_feat_f32(_p(xb), _p(yb), _p(dist), _p(idx), xb.shape[0], N, M, C, int(k))
     return dist.reshape(lead + (N, k)), idx.reshape(lead + (N, k))
+
+
+def radius_search_pack(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit):
+    """Pack-mode radius search (ops/radius_search.py:44-71): (total_q, limit) i64, absent = total_s."""
+    q = _c(q_points, np.float32)
+    s = _c(s_points, np.float32)
+    ql = _c(q_lengths, np.int64)
+    sl = _c(s_lengths, np.int64)
+    out = np.zeros((q.shape[0], int(neighbor_limit)), dtype=np.int64)
+    lib().v3d_oracle_radius_search_pack_f32(
+        _p(q), _p(s), _p(ql), _p(sl), _p(out), int(ql.shape[0]), ctypes.c_int64(s.shape[0]), ctypes.c_float(radius),
+        int(neighbor_limit),
+    )
+    return out
+
+
+def grid_subsample_pack(points, lengths, voxel_size):
+    """Pack-mode grid subsampling (ops/grid_subsample.py:49-99): (sampled_points (M,3) f32, sampled_lengths (B,) i64)."""
+    p = _c(points, np.float32)
+    ln = _c(lengths, np.int64)
+    out = np.zeros((max(p.shape[0], 1), 3), dtype=np.float32)
+    out_len = np.zeros((ln.shape[0],), dtype=np.int64)
+    fn = lib().v3d_oracle_grid_subsample_pack_f32
+    fn.restype = ctypes.c_int64
+    m = fn(_p(p), _p(ln), int(ln.shape[0]), ctypes.c_float(voxel_size), _p(out), _p(out_len))
+    return out[:m].copy(), out_len

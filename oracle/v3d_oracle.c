@@ -378,3 +378,116 @@ void v3d_oracle_knn_feat_f32(const float* x, const float* y, float* kd, int64_t*
     free(bi);
   }
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * "next" rows: pack-mode radius search and grid subsampling.
+ * --------------------------------------------------------------------------------------------------------- */
+
+/* Radius search in pack mode, restated from ops/radius_search.py:44-71: per cloud keops_knn(limit) (pykeops,
+ * third-party and absent -> "parity unpinned": ascending Euclidean distance, equal distances by lower index), then
+ * `knn_indices.masked_fill_(knn_distances > radius, total_s)` (:66-67), supports offset by the cloud's start (:64-65).
+ * Equivalent statement used here: the supports of the query's own cloud with NOT(sqrtf(d2) > radius), ascending by
+ * (d2, index), first `limit`, padded with total_s.  d2 = (dx*dx + dy*dy) + dz*dz in float, one rounding per operation.
+ * q (total_q,3) s (total_s,3) lengths (B,) -> out (total_q, limit). */
+typedef struct {
+  float d;
+  int64_t i;
+} v3d_hit_t;
+
+static int v3d_hit_cmp(const void* a, const void* b) {
+  const v3d_hit_t* x = (const v3d_hit_t*)a;
+  const v3d_hit_t* y = (const v3d_hit_t*)b;
+  if (x->d < y->d) return -1;
+  if (x->d > y->d) return 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+
+void v3d_oracle_radius_search_pack_f32(const float* q, const float* s, const int64_t* q_len, const int64_t* s_len,
+                                       int64_t* out, int B, int64_t total_s, float radius, int limit) {
+  int64_t q_off = 0, s_off = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t nq = q_len[b], ns = s_len[b];
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+    for (int64_t a = 0; a < nq; ++a) {
+      const float* qp = q + (size_t)(q_off + a) * 3;
+      v3d_hit_t* hits = (v3d_hit_t*)malloc(sizeof(v3d_hit_t) * (size_t)(ns > 0 ? ns : 1));
+      int64_t cnt = 0;
+      for (int64_t j = 0; j < ns; ++j) {
+        const float* sp = s + (size_t)(s_off + j) * 3;
+        float dx = qp[0] - sp[0], dy = qp[1] - sp[1], dz = qp[2] - sp[2];
+        float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (!(sqrtf(d2) > radius)) {
+          hits[cnt].d = d2;
+          hits[cnt].i = s_off + j;
+          ++cnt;
+        }
+      }
+      qsort(hits, (size_t)cnt, sizeof(v3d_hit_t), v3d_hit_cmp);
+      for (int n = 0; n < limit; ++n) out[(size_t)(q_off + a) * limit + n] = n < cnt ? hits[n].i : total_s;
+      free(hits);
+    }
+    q_off += nq;
+    s_off += ns;
+  }
+}
+
+/* Grid subsampling in pack mode, restated from ops/grid_subsample.py:49-99: voxel = floor(point * float(1/voxel_size))
+ * (:64-65, float32 product), minus the cloud's minimum voxel (:75); one output point per occupied voxel, ordered like
+ * torch.unique of the raveled (cloud, vx, vy, vz) hash (:82-85), i.e. by cloud then lexicographically; its value is the
+ * float32 sum of the voxel's points in input order (scatter_add_ on one CPU thread, :88) divided by the count (:89).
+ * (The reference's CUDA scatter_add_ uses float atomics: its summation order is not defined.)
+ * points (total,3) lengths (B,) -> out_points (<= total,3) out_lengths (B,); returns the number of output points. */
+typedef struct {
+  int64_t vx, vy, vz, idx;
+} v3d_vox_t;
+
+static int v3d_vox_cmp(const void* a, const void* b) {
+  const v3d_vox_t* x = (const v3d_vox_t*)a;
+  const v3d_vox_t* y = (const v3d_vox_t*)b;
+  if (x->vx != y->vx) return x->vx < y->vx ? -1 : 1;
+  if (x->vy != y->vy) return x->vy < y->vy ? -1 : 1;
+  if (x->vz != y->vz) return x->vz < y->vz ? -1 : 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+int64_t v3d_oracle_grid_subsample_pack_f32(const float* points, const int64_t* lengths, int B, float voxel_size,
+                                           float* out_points, int64_t* out_lengths) {
+  const float inv = (float)(1.0 / (double)voxel_size); /* :64 python float, cast to the tensor's dtype by the product */
+  int64_t off = 0, m = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = lengths[b];
+    v3d_vox_t* v = (v3d_vox_t*)malloc(sizeof(v3d_vox_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) {
+      const float* p = points + (size_t)(off + i) * 3;
+      v[i].vx = (int64_t)floorf(p[0] * inv);
+      v[i].vy = (int64_t)floorf(p[1] * inv);
+      v[i].vz = (int64_t)floorf(p[2] * inv);
+      v[i].idx = i;
+    }
+    /* subtracting the per-cloud minimum (:75) does not change the order or the grouping */
+    qsort(v, (size_t)n, sizeof(v3d_vox_t), v3d_vox_cmp);
+    int64_t count = 0, i = 0;
+    while (i < n) {
+      int64_t j = i;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      while (j < n && v[j].vx == v[i].vx && v[j].vy == v[i].vy && v[j].vz == v[i].vz) {
+        const float* p = points + (size_t)(off + v[j].idx) * 3;
+        sx += p[0];
+        sy += p[1];
+        sz += p[2];
+        ++j;
+      }
+      const float c = (float)(j - i);
+      out_points[(size_t)m * 3 + 0] = sx / c;
+      out_points[(size_t)m * 3 + 1] = sy / c;
+      out_points[(size_t)m * 3 + 2] = sz / c;
+      ++m;
+      ++count;
+      i = j;
+    }
+    out_lengths[b] = count;
+    free(v);
+    off += n;
+  }
+  return m;
+}

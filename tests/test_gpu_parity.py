@@ -568,3 +568,50 @@ def test_topk_merge_equals_single_shot(ext, oracle_mod):
     oi = torch.empty((300, k), dtype=torch.long, device=DEV)
     ext.topk_merge(pd, pi, od, oi)
     assert torch.equal(oi, full_i[0]) and torch.equal(od, full_d[0])
+
+
+# ------------------------------------------------------------------------------------------------------
+# "next" rows: native pack-mode radius search
+# ------------------------------------------------------------------------------------------------------
+def _pack_clouds(rng, q_lens, s_lens, lattice=None, scale=1.0):
+    def cloud(n):
+        if lattice:
+            return (rng.integers(0, lattice, (n, 3)) * (scale / lattice)).astype(np.float32)
+        return (rng.random((n, 3)) * scale).astype(np.float32)
+
+    q = np.concatenate([cloud(n) for n in q_lens] + [np.zeros((0, 3), np.float32)])
+    s = np.concatenate([cloud(n) for n in s_lens] + [np.zeros((0, 3), np.float32)])
+    return q, s, np.asarray(q_lens, np.int64), np.asarray(s_lens, np.int64)
+
+
+@pytest.mark.parametrize("case", [
+    dict(q=(300, 0, 200), s=(500, 10, 400), r=0.15, k=20),          # empty query cloud, tiny support cloud
+    dict(q=(64, 1, 1000), s=(0, 7, 3000), r=0.1, k=38),             # empty support cloud -> all sentinel
+    dict(q=(500,), s=(500,), r=0.3, k=100, lattice=8),              # lattice: massive (d2, index) ties, R = 2 list
+    dict(q=(400, 400), s=(2000, 1500), r=0.05, k=5),                # hits << limit and hits >> limit mix
+    dict(q=(300,), s=(4000,), r=2.0, k=64),                         # radius covers the whole cloud: one coarse cell
+    dict(q=(200, 200), s=(3000, 3000), r=0.0625, k=38, scale=3.0),  # config-4-like proportions
+    dict(q=(100,), s=(100,), r=0.0, k=4, lattice=4),                # zero radius: only coincident points
+])
+def test_radius_search_pack_native(ext, oracle_mod, case):
+    rng = np.random.default_rng(61)
+    q, s, ql, sl = _pack_clouds(rng, case["q"], case["s"], case.get("lattice"), case.get("scale", 1.0))
+    want = oracle_mod.radius_search_pack(q, s, ql, sl, case["r"], case["k"])
+    out = torch.full((q.shape[0], case["k"]), -7, dtype=torch.long, device=DEV)
+    ext.radius_search_pack(T(q), T(s), T(ql), T(sl), out, case["r"], case["k"])
+    assert np.array_equal(N_(out), want)
+
+
+def test_radius_search_pack_mode_op_matches_padded_route(ext, oracle_mod):
+    """ops.radius_search_pack_mode (native) == the reference's formulation (kNN over padded batches + mask) on
+    tie-free inputs, and queries outside the supports' bounding box are handled."""
+    from vision3d_amd import ops
+    from vision3d_amd.ops.radius_search import padded_radius_search_pack_mode
+
+    rng = np.random.default_rng(62)
+    q, s, ql, sl = _pack_clouds(rng, (257, 300), (900, 1100))
+    q[:20] += 0.9  # outside the support box
+    a = ops.radius_search_pack_mode(T(q), T(s), T(ql), T(sl), 0.2, 30)
+    b = padded_radius_search_pack_mode(T(q), T(s), T(ql), T(sl), 0.2, 30)
+    assert torch.equal(a, b)
+    assert np.array_equal(N_(a), oracle_mod.radius_search_pack(q, s, ql, sl, 0.2, 30))

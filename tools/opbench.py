@@ -96,6 +96,15 @@ def main():
         i = torch.empty((B, N, k), dtype=torch.long, device=DEV)
         add(f"knn_feat B{B} N{N} M{M} C{C} k{k}", lambda x=x, y=y, d=d, i=i, k=k: ext.knn_feat(x, y, d, i, k),
             2.0 * B * N * M * C / 1e6, "TFLOP/s")
+    # config 4 (KPConv / GeoTransformer pyramid stage): 16 clouds of 30,000 points in a 3 x 3 x 2.5 m box, pack mode
+    for (nc, n, r, lim) in ((16, 30000, 0.0625, 38), (16, 30000, 0.2, 38)):
+        pts = (torch.rand((nc * n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
+        lengths = torch.full((nc,), n, dtype=torch.long, device=DEV)
+        out = torch.empty((nc * n, lim), dtype=torch.long, device=DEV)
+        add(f"radius_search_pack clouds{nc} n{n} r{r} limit{lim}",
+            lambda pts=pts, lengths=lengths, out=out, r=r, lim=lim: ext.radius_search_pack(pts, pts, lengths, lengths,
+                                                                                           out, r, lim),
+            nc * n, "Mq/s")
     for name, fn, work, unit in cases:
         med, mn = timeit(fn)
         rate = (work / (med * 1e-3) / 1e6) if work else 0.0  # work/1e6 per second

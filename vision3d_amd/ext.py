@@ -312,3 +312,24 @@ def topk_merge(parts_distances, parts_indices, distances, indices):
     _lib.check(_lib.lib().v3d_topk_merge_f32(parts_distances.data_ptr(), parts_indices.data_ptr(),
                                              distances.data_ptr(), indices.data_ptr(), G, rows, k, dev, stream),
                "topk_merge")
+
+
+def radius_search_pack(q_points, s_points, q_lengths, s_lengths, neighbor_indices, radius, neighbor_limit):
+    """q_points (M,3), s_points (N,3) fp32; lengths (B,) int64 on the same device; neighbor_indices (M, limit) int64."""
+    for t, name in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"),
+                    (s_lengths, "s_lengths"), (neighbor_indices, "neighbor_indices")):
+        _check_cuda_contiguous(t, name)
+    _check_float(q_points, "q_points")
+    _check_float(s_points, "s_points")
+    for t, name in ((q_lengths, "q_lengths"), (s_lengths, "s_lengths"), (neighbor_indices, "neighbor_indices")):
+        _check_long(t, name)
+    B = q_lengths.shape[0]
+    if s_lengths.shape[0] != B:
+        raise RuntimeError("q_lengths and s_lengths must have the same number of clouds")
+    M, N = q_points.shape[0], s_points.shape[0]
+    dev, stream = _where(q_points)
+    ws = _workspace(_lib.lib().v3d_radius_search_workspace_bytes(B, N), q_points)
+    rc = _lib.lib().v3d_radius_search_pack_f32(
+        q_points.data_ptr(), s_points.data_ptr(), q_lengths.data_ptr(), s_lengths.data_ptr(),
+        neighbor_indices.data_ptr(), B, M, N, float(radius), int(neighbor_limit), ws.data_ptr(), ws.numel(), dev, stream)
+    _lib.check(rc, "radius_search_pack_mode")

@@ -11,7 +11,22 @@ from .knn import keops_knn
 
 
 def radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, inf=1e10):
-    """q_points (M, 3), s_points (N, 3), lengths (B,) -> neighbor indices (M, neighbor_limit), N where absent."""
+    """q_points (M, 3), s_points (N, 3), lengths (B,) -> neighbor indices (M, neighbor_limit), N where absent.
+
+    Native pack-mode kernel (uniform-grid cell list, no padding, no host synchronisation).  fp32 3-D points with
+    ``neighbor_limit <= 128``; anything else takes the reference's route (kNN over padded batches + mask).  ``inf`` is
+    only used by that route."""
+    if (q_points.dtype == torch.float32 and s_points.dtype == torch.float32 and q_points.shape[-1] == 3
+            and 0 < neighbor_limit <= 128):
+        out = torch.empty((q_points.shape[0], neighbor_limit), dtype=torch.long, device=q_points.device)
+        ext.radius_search_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.contiguous(),
+                               s_lengths.contiguous(), out, radius, neighbor_limit)
+        return out
+    return padded_radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, inf)
+
+
+def padded_radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, inf=1e10):
+    """The reference's formulation (radius_search.py:58-70): kNN over padded batches, then the distance mask."""
     batch_q_points, batch_q_masks = pack_to_batch(q_points, q_lengths, fill_value=inf)  # (B, M', 3)
     batch_s_points, _ = pack_to_batch(s_points, s_lengths, fill_value=inf)  # (B, N', 3)
     batch_knn_distances, batch_knn_indices = keops_knn(batch_q_points, batch_s_points, neighbor_limit)
