@@ -169,6 +169,15 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
                                int64_t total_s, float radius, int neighbor_limit, void* workspace,
                                size_t workspace_bytes, int device, void* stream);
 
+/* Grid (voxel) subsampling, replaces vision3d/ops/grid_subsample.py:49-99: one output point per occupied voxel of
+ * edge `voxel_size` = mean of the voxel's points (summed in input order, fp32), ordered by (cloud, vx, vy, vz) like
+ * torch.unique of the reference's hash.  sampled_points must hold `total` rows; the number actually written goes to
+ * *num_sampled (device scalar; -1 if a cloud spans more than 2^18 voxels along an axis or holds NaN), per-cloud
+ * counts to sampled_lengths (B,).  Scratch is allocated stream-ordered inside (hipMallocAsync). */
+int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, float* sampled_points,
+                                int64_t* sampled_lengths, int64_t* num_sampled, int B, int64_t total, float voxel_size,
+                                int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

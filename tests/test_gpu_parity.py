@@ -615,3 +615,23 @@ def test_radius_search_pack_mode_op_matches_padded_route(ext, oracle_mod):
     b = padded_radius_search_pack_mode(T(q), T(s), T(ql), T(sl), 0.2, 30)
     assert torch.equal(a, b)
     assert np.array_equal(N_(a), oracle_mod.radius_search_pack(q, s, ql, sl, 0.2, 30))
+
+
+@pytest.mark.parametrize("case", [
+    dict(lens=(700, 0, 300), vs=0.25, scale=2.0, shift=-0.5),
+    dict(lens=(5000,), vs=0.05, scale=1.0, shift=0.0),
+    dict(lens=(1, 1, 1), vs=0.1, scale=1.0, shift=0.0),
+    dict(lens=(3000, 2000), vs=10.0, scale=1.0, shift=-3.0),        # every cloud collapses into <= 8 voxels: long runs
+    dict(lens=(4000,), vs=0.03, scale=1.0, shift=100.0),            # far from the origin
+])
+def test_grid_subsample_pack_native(ext, oracle_mod, case):
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(71)
+    n = sum(case["lens"])
+    pts = (rng.random((n, 3)) * case["scale"] + case["shift"]).astype(np.float32)
+    lengths = np.asarray(case["lens"], np.int64)
+    want_p, want_l = oracle_mod.grid_subsample_pack(pts, lengths, case["vs"])
+    got_p, got_l = ops.grid_subsample_pack_mode(T(pts), T(lengths), case["vs"])
+    assert np.array_equal(N_(got_l), want_l)
+    assert np.array_equal(N_(got_p), want_p)  # same order, same summation order: bit-identical

@@ -105,6 +105,16 @@ def main():
             lambda pts=pts, lengths=lengths, out=out, r=r, lim=lim: ext.radius_search_pack(pts, pts, lengths, lengths,
                                                                                            out, r, lim),
             nc * n, "Mq/s")
+    for (nc, n, vs) in ((16, 30000, 0.025), (16, 30000, 0.1)):
+        pts = (torch.rand((nc * n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
+        lengths = torch.full((nc,), n, dtype=torch.long, device=DEV)
+        o = torch.empty_like(pts)
+        ol = torch.empty_like(lengths)
+        num = torch.zeros((), dtype=torch.long, device=DEV)
+        add(f"grid_subsample_pack clouds{nc} n{n} voxel{vs}",
+            lambda pts=pts, lengths=lengths, o=o, ol=ol, num=num, vs=vs: ext.grid_subsample_pack(pts, lengths, o, ol,
+                                                                                                 num, vs),
+            nc * n, "Mpts/s")
     for name, fn, work, unit in cases:
         med, mn = timeit(fn)
         rate = (work / (med * 1e-3) / 1e6) if work else 0.0  # work/1e6 per second

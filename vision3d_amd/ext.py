@@ -333,3 +333,21 @@ def radius_search_pack(q_points, s_points, q_lengths, s_lengths, neighbor_indice
         q_points.data_ptr(), s_points.data_ptr(), q_lengths.data_ptr(), s_lengths.data_ptr(),
         neighbor_indices.data_ptr(), B, M, N, float(radius), int(neighbor_limit), ws.data_ptr(), ws.numel(), dev, stream)
     _lib.check(rc, "radius_search_pack_mode")
+
+
+def grid_subsample_pack(points, lengths, sampled_points, sampled_lengths, num_sampled, voxel_size):
+    """points (N,3) fp32, lengths (B,) int64 -> sampled_points (N,3) capacity, sampled_lengths (B,), num_sampled ()."""
+    for t, name in ((points, "points"), (lengths, "lengths"), (sampled_points, "sampled_points"),
+                    (sampled_lengths, "sampled_lengths"), (num_sampled, "num_sampled")):
+        _check_cuda_contiguous(t, name)
+    _check_float(points, "points")
+    _check_float(sampled_points, "sampled_points")
+    for t, name in ((lengths, "lengths"), (sampled_lengths, "sampled_lengths"), (num_sampled, "num_sampled")):
+        _check_long(t, name)
+    if sampled_points.shape[0] < points.shape[0] or sampled_lengths.shape[0] != lengths.shape[0]:
+        raise RuntimeError("grid_subsample_pack: output buffers too small")
+    dev, stream = _where(points)
+    rc = _lib.lib().v3d_grid_subsample_pack_f32(
+        points.data_ptr(), lengths.data_ptr(), sampled_points.data_ptr(), sampled_lengths.data_ptr(),
+        num_sampled.data_ptr(), lengths.shape[0], points.shape[0], float(voxel_size), dev, stream)
+    _lib.check(rc, "grid_subsample_pack_mode")

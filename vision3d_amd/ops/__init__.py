@@ -13,6 +13,7 @@ from .group_gather import group_gather
 from .knn import knn, knn_pack_mode
 from .knn_points import knn_points
 from .pairwise_distance import pairwise_distance
+from .grid_subsample import grid_subsample_pack_mode
 from .radius_search import radius_count_pack_mode, radius_search_pack_mode
 from .three_interpolate import three_interpolate
 from .three_nn import three_nn
@@ -20,5 +21,5 @@ from .three_nn import three_nn
 __all__ = [
     "ball_query", "batch_to_pack", "batch_to_pack_with_lengths", "pack_to_batch", "furthest_point_sample", "gather",
     "group_gather", "knn", "knn_pack_mode", "knn_points", "pairwise_distance", "radius_count_pack_mode",
-    "radius_search_pack_mode", "three_interpolate", "three_nn",
+    "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
 ]
