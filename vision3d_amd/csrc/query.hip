@@ -396,6 +396,28 @@ __device__ __forceinline__ double lane_permute(double v, int dst_lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// (k+1)-th smallest (k = 0..63) of the 64 lanes' non-negative values, or an upper bound of it that is exact in the
+// leading 32 bits: bit-wise binary search on the IEEE pattern (order-preserving for non-negative numbers), one
+// compare + ballot + popcount per bit.  Returns +inf when fewer than k+1 lanes hold a finite value.
+__device__ __forceinline__ float kth_smallest_upper(float v, int k) {
+  const unsigned bits = __float_as_uint(v);
+  unsigned prefix = 0;
+  for (int b = 30; b >= 0; --b) {  // sign bit is 0
+    const unsigned trial = prefix | (1u << b);
+    if (__builtin_popcountll(__ballot(bits < trial)) <= k) prefix = trial;  // the answer is >= trial
+  }
+  return __uint_as_float(prefix);
+}
+__device__ __forceinline__ double kth_smallest_upper(double v, int k) {
+  const unsigned hi = (unsigned)(__double_as_longlong(v) >> 32);
+  unsigned prefix = 0;
+  for (int b = 30; b >= 0; --b) {
+    const unsigned trial = prefix | (1u << b);
+    if (__builtin_popcountll(__ballot(hi < trial)) <= k) prefix = trial;
+  }
+  return __longlong_as_double(((long long)prefix << 32) | 0xffffffffll);  // largest double with these high bits
+}
+
 template <typename T, int R>
 struct LaneList {
   T d[R];
@@ -492,7 +514,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
   const T* s_cloud = s + (int64_t)b * N * 3;
   const T sentinel = static_cast<T>(1e10);  // knn_points_cuda.cuh:71: nothing >= 1e10 ever enters
 
-  T qx[QPW], qy[QPW], qz[QPW], tau[QPW];
+  T qx[QPW], qy[QPW], qz[QPW], tau[QPW], capk[QPW];
   LaneList<T, R> list[QPW];
 #pragma unroll
   for (int g = 0; g < QPW; ++g) {
@@ -503,6 +525,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
     qy[g] = qp[1];
     qz[g] = qp[2];
     tau[g] = live ? sentinel : static_cast<T>(-1);  // dead slot: nothing ever beats -1
+    capk[g] = INFINITY;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       list[g].d[r] = sentinel;
@@ -515,6 +538,28 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
     __syncthreads();
     stage_supports_aos(s_cloud, t0, tcount, tile);
     __syncthreads();
+    if (t0 == 0 && R == 1 && tcount >= 256) {
+      // Pre-pass over the first tile: every lane takes the minimum distance of its own supports; the (k+1)-th
+      // smallest of those 64 minima bounds the (k+1)-th smallest distance from above (64 distinct supports attain
+      // them), usually tightly, so the list does not start by admitting whole chunks.  Everything <= the bound is still
+      // admitted, in index order, so the k+1 best and their order among equals are unchanged.
+      T lmin[QPW];
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) lmin[g] = INFINITY;
+      for (int c0 = 0; c0 < tcount; c0 += 64) {
+        const int j = c0 + lane;
+        const bool valid = j < tcount;
+        const int jj = valid ? j : 0;
+        const T sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+#pragma unroll
+        for (int g = 0; g < QPW; ++g) {
+          const T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
+          lmin[g] = (valid && d < lmin[g]) ? d : lmin[g];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) capk[g] = kth_smallest_upper(lmin[g], k);
+    }
     for (int c0 = 0; c0 < tcount; c0 += 64) {
       const int j = c0 + lane;
       const bool valid = j < tcount;
@@ -524,7 +569,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
 #pragma unroll
       for (int g = 0; g < QPW; ++g) {
         const T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
-        if (first_chunk && tau[g] == sentinel) {
+        if (first_chunk && tau[g] == sentinel && !(capk[g] < INFINITY)) {
           // empty list: rank-sort the whole chunk straight into it instead of 64 serial insertions
           const bool real = valid && d < sentinel;
           const T dm = real ? d : sentinel;
@@ -539,12 +584,12 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
           tau[g] = list[g].at(k);
           continue;
         }
-        unsigned long long m = __ballot(valid && d < tau[g]);
+        unsigned long long m = __ballot(valid && d < tau[g] && d <= capk[g]);
         while (m) {
           const int l = __builtin_ffsll((long long)m) - 1;
           list[g].insert(read_lane(d, l), t0 + c0 + l, lane);
           tau[g] = list[g].at(k);
-          m = __ballot(valid && d < tau[g]) & ~((2ull << l) - 1ull);
+          m = __ballot(valid && d < tau[g] && d <= capk[g]) & ~((2ull << l) - 1ull);
         }
       }
     }
