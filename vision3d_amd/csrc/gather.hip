@@ -1,18 +1,16 @@
-// gather.hip -- gather / group_gather forward (any element width) and the atomic-free backward shared with
-// three_interpolate.  Replaces gather_cuda.cuh / group_gather_cuda.cuh / the backward half of
-// three_interpolate_cuda.cuh of the reference (semantics only; the design is gfx950-first).
+// gather.hip -- gather / group_gather forward (any element width).  Replaces the forward kernels of gather_cuda.cuh:11-33
+// and group_gather_cuda.cuh:11-33 of the reference (semantics only; the design is gfx950-first).  The
+// backward lives in scatter.hip.
 //
-// Forward  out[b,c,t] = src[b,c,idx[b,t]]  (t runs over the M resp. M*K flat target positions):
-//   HBM-write bound.  One workgroup owns a tile of target positions of one cloud and walks a TILE OF
-//   CHANNELS with the indices held in registers (the reference re-reads the int64 index tensor once per
-//   channel).  Stores are 16 B per lane.  Two source paths:
-//     * lds   : the (b,c) source row is staged in LDS (double buffered, one barrier per channel) and the
-//               random 4-byte reads hit LDS banks instead of the vector L1;
+// out[b,c,t] = src[b,c,idx[b,t]]  (t runs over the M resp. M*K flat target positions): HBM-write bound.
+//   One workgroup owns a tile of target positions of one cloud and walks a TILE OF CHANNELS with the indices held in
+//   registers (the reference re-reads the int64 index tensor once per channel).  Stores are 16 B per lane, 1 KiB
+//   contiguous per wave.  Two source paths:
+//     * lds   : the (b,c) source row is staged in LDS (double buffered, the next row's loads in flight, one barrier
+//               per channel) and the random 4-byte reads hit LDS banks instead of the vector L1;
 //     * direct: rows too large for LDS are gathered straight from global memory (L2-resident).
-// Backward grad_src[b,c,n] = sum_{t: idx[b,t]==n} grad_out[b,c,t]:
-//   the index tensor is inverted once per call into a CSR (count -> scan -> fill -> rank-sort, 32-bit
-//   integer atomics only on the tiny count/cursor arrays), then every (b,c,n) is summed by ONE thread in
-//   ascending t.  No float atomics, bit-reproducible, equal to the sequential CPU loop.
+//   Workgroups of one cloud are placed on one XCD (GridMap, common.h) so that source rows and index tiles are fetched
+//   from HBM once.
 #include "common.h"
 
 namespace v3d {
