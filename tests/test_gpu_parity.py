@@ -635,3 +635,37 @@ def test_grid_subsample_pack_native(ext, oracle_mod, case):
     got_p, got_l = ops.grid_subsample_pack_mode(T(pts), T(lengths), case["vs"])
     assert np.array_equal(N_(got_l), want_l)
     assert np.array_equal(N_(got_p), want_p)  # same order, same summation order: bit-identical
+
+
+def test_feature_knn_full_config_sizes(ext, oracle_mod):
+    """C3 (DGCNN EdgeConv: 32 x 1024 x 64, k = 20, self included) against the oracle at full size, and a C5-shaped
+    reference-set shard (normalised 256-d features, 100k supports) through size-independent properties: the planted
+    nearest neighbour is found, rows are sorted, and the distances equal the exact difference form."""
+    rng = np.random.default_rng(81)
+    oracle_mod.set_threads(oracle_mod.max_threads())
+    try:
+        x = rng.standard_normal((32, 1024, 64)).astype(np.float32)
+        wd, wi = oracle_mod.knn_feat(x, x, 20)
+    finally:
+        oracle_mod.set_threads(1)
+    d = torch.empty((32, 1024, 20), device=DEV)
+    idx = torch.empty((32, 1024, 20), dtype=torch.long, device=DEV)
+    ext.knn_feat(T(x), T(x), d, idx, 20)
+    gd, gi = N_(d), N_(idx)
+    scale = 2.0 * (x ** 2).sum(-1).max()
+    assert np.all(gi[..., 0] == np.arange(1024)) and np.all(np.abs(gd - wd) <= 1e-5 * scale)
+    assert (gi != wi).mean() < 1e-4  # only exact near-ties may swap
+    # C5 shard: y = 100k unit vectors, x = 2048 of them plus noise -> neighbour 0 is the planted one
+    n, m, c, k = 2048, 100000, 256, 3
+    g = torch.Generator(device="cpu").manual_seed(5)
+    y = torch.nn.functional.normalize(torch.randn((1, m, c), generator=g), dim=-1)
+    planted = torch.randint(0, m, (n,), generator=g)
+    xq = torch.nn.functional.normalize(y[0, planted] + 0.01 * torch.randn((n, c), generator=g), dim=-1)[None]
+    yd, xd = y.to(DEV).contiguous(), xq.to(DEV).contiguous()
+    d = torch.empty((1, n, k), device=DEV)
+    idx = torch.empty((1, n, k), dtype=torch.long, device=DEV)
+    ext.knn_feat(xd, yd, d, idx, k)
+    assert torch.equal(idx[0, :, 0].cpu(), planted)
+    assert torch.all(d[..., 1:] >= d[..., :-1])
+    exact = (xd[0, :, None, :] - yd[0][idx[0]]).pow(2).sum(-1).sqrt()  # (n, k) exact difference form
+    torch.testing.assert_close(d[0], exact, rtol=0, atol=2e-5)
