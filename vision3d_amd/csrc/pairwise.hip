@@ -241,9 +241,12 @@ __device__ __forceinline__ float wave_shr1(float v) {
 }
 __device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 
+constexpr int kTopkCand = 192;  // candidates ranked in LDS per row
+
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ D, int64_t rows, int ncols,
                                                         int64_t ld, int col_base, int k, int first_chunk,
                                                         float* __restrict__ run_d, int* __restrict__ run_i) {
+  __shared__ float2 cand_s[4][kTopkCand];
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -265,15 +268,49 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       const int c = c0 + lane;
       lmin = fminf(lmin, c < ncols ? drow[c] : INFINITY);
     }
-    int rank = 0;
-    for (int o = 0; o < 64; ++o) {
-      const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmin), o));
-      rank += (v < lmin || (v == lmin && o < lane)) ? 1 : 0;
+    // k-th smallest of the 64 minima (distances are >= 0, so the IEEE pattern orders like an integer): bit-wise binary
+    // search, one compare + ballot + popcount per bit
+    const unsigned lbits = __float_as_uint(lmin);
+    unsigned prefix = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+      const unsigned trial = prefix | (1u << bit);
+      if (__builtin_popcountll(__ballot(lbits < trial)) <= k - 1) prefix = trial;
     }
-    const unsigned long long sel = __ballot(rank == k - 1);  // ranks are a permutation: exactly one lane
-    const float kth = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmin), __builtin_ffsll((long long)sel) - 1));
+    const float kth = __uint_as_float(prefix);
     // strict '<' below must still admit values equal to the bound: step to the next float (kth >= 0)
     cap = kth < INFINITY ? __uint_as_float(__float_as_uint(kth) + 1u) : INFINITY;
+  }
+  // Whole row in one chunk and a finite bound: the columns below the bound (a few more than k, usually) are collected
+  // in LDS and ranked against each other in one go -- every lane ranks one candidate by (distance, column) -- instead
+  // of one whole-wave shift per candidate.  More than kTopkCand candidates: the insertion path below takes the row.
+  if (first_chunk && cap < INFINITY) {
+    float2* cand = cand_s[threadIdx.x >> 6];
+    int count = 0;
+    for (int c0 = 0; c0 < ncols && count <= kTopkCand; c0 += 64) {
+      const int c = c0 + lane;
+      const float d = c < ncols ? drow[c] : INFINITY;
+      const unsigned long long m = __ballot(d < cap);
+      const int slot = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (d < cap && slot < kTopkCand) cand[slot] = make_float2(d, __int_as_float(col_base + c));
+      count += __builtin_popcountll(m);
+    }
+    if (count <= kTopkCand) {  // count >= k: the bound is attained by k distinct columns
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int j0 = 0; j0 < count; j0 += 64) {
+        const int j = j0 + lane;
+        const float2 me = cand[j < count ? j : 0];
+        int rank = 0;
+        for (int i = 0; i < count; ++i) {
+          const float2 o = cand[i];  // same address in every lane: LDS broadcast
+          rank += (o.x < me.x || (o.x == me.x && __float_as_int(o.y) < __float_as_int(me.y))) ? 1 : 0;
+        }
+        if (j < count && rank < k) {
+          run_d[row * k + rank] = me.x;
+          run_i[row * k + rank] = __float_as_int(me.y);
+        }
+      }
+      return;
+    }
   }
   float tau = fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1)), cap);
   for (int c0 = 0; c0 < ncols; c0 += 64) {
@@ -318,6 +355,14 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // sum over the 64 lan
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+__device__ __forceinline__ float row16_sum_f32(float v) {  // sum over each row of 16 lanes, in every lane of the row
+  V3D_DPP_ADD(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_ADD(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  V3D_DPP_ADD(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+  V3D_DPP_ADD(v, "row_mirror row_mask:0xf bank_mask:0xf");
+  return v;
+}
+
 // Final pass: recompute the k selected distances exactly as sqrt(sum_c (x_c - y_c)^2) (what pykeops evaluates,
 // ops/knn.py:25), re-rank by (distance, index) and write fp32 distances + int64 (offset) indices.
 // One wave per query row; for each selected neighbour the 64 lanes split the channels (coalesced row reads) and
@@ -325,7 +370,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // sum over the 64 lan
 __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                 const float* __restrict__ run_d,
                                                                 const int* __restrict__ run_i, int batch, int N, int M,
-                                                                int C, int k, int64_t index_offset,
+                                                                int C, int k, int64_t index_offset, int vec4,
                                                                 float* __restrict__ out_d, int64_t* __restrict__ out_i) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -334,17 +379,42 @@ __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __r
   const int idx = lane < k ? run_i[row * k + lane] : -1;
   float dist = INFINITY;
   const float* xr = x + row * C;
-  for (int j = 0; j < k; ++j) {
-    const int ij = __builtin_amdgcn_readlane(idx, j);  // wave-uniform
-    if (ij < 0) continue;
-    const float* yr = y + ((int64_t)b * M + ij) * C;
-    float part = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float df = xr[c] - yr[c];
-      part = __builtin_fmaf(df, df, part);
+  if (vec4) {
+    // four neighbours at a time: a row of 16 lanes owns one neighbour and reads its features as 16-byte pieces;
+    // the four DPP steps that stay inside a row of 16 lanes leave every lane of the row with its neighbour's sum
+    const int l16 = lane & 15, grp = lane >> 4;
+    for (int j0 = 0; j0 < k; j0 += 4) {
+      const int ij = __shfl(idx, min(j0 + grp, 63), 64);
+      const bool live = (j0 + grp < k) && ij >= 0;
+      const float* yr = y + ((int64_t)b * M + (live ? ij : 0)) * C;
+      float part = 0.f;
+      for (int c = l16 * 4; c < C; c += 64) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        const float4 yv = *reinterpret_cast<const float4*>(yr + c);
+        const float d0 = xv.x - yv.x, d1 = xv.y - yv.y, d2 = xv.z - yv.z, d3 = xv.w - yv.w;
+        part = __builtin_fmaf(d0, d0, part);
+        part = __builtin_fmaf(d1, d1, part);
+        part = __builtin_fmaf(d2, d2, part);
+        part = __builtin_fmaf(d3, d3, part);
+      }
+      const float tot = row16_sum_f32(part);
+      const float mine = __shfl(live ? tot : INFINITY, (lane & 3) << 4, 64);  // neighbour j0 + (lane & 3)
+      if ((lane >> 2) == (j0 >> 2)) dist = sqrtf(mine);  // lane L keeps neighbour L
     }
-    const float tot = wave_sum_f32(part);
-    if (lane == j) dist = sqrtf(tot);
+    if (idx < 0) dist = INFINITY;
+  } else {
+    for (int j = 0; j < k; ++j) {
+      const int ij = __builtin_amdgcn_readlane(idx, j);  // wave-uniform
+      if (ij < 0) continue;
+      const float* yr = y + ((int64_t)b * M + ij) * C;
+      float part = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float df = xr[c] - yr[c];
+        part = __builtin_fmaf(df, df, part);
+      }
+      const float tot = wave_sum_f32(part);
+      if (lane == j) dist = sqrtf(tot);
+    }
   }
   // rank sort among the k entries (k <= 64): position = number of entries that precede mine
   int rank = 0;
@@ -506,8 +576,9 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
     rc = launch_status(what);
   }
   if (rc == 0) {
+    const int vec4 = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     hipLaunchKernelGGL(knn_feat_finalize_kernel, dim3(row_blocks), dim3(256), 0, stream, x, y, ws.run_d, ws.run_i,
-                       batch, N, Mw, C, k, index_offset, distances, indices);
+                       batch, N, Mw, C, k, index_offset, vec4, distances, indices);
     rc = launch_status(what);
   }
   if (own) {
