@@ -261,12 +261,26 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   // columns; the k-th smallest of those 64 minima is an upper bound of the row's k-th smallest distance, usually a
   // tight one, and caps the insertion threshold from the start (an empty list would otherwise admit every column
   // of the first chunks).  Costs one extra read of the row (L2 / Infinity-Cache resident).
+  // Both passes read the row in tiles of 1024 columns, four 16-byte loads per lane issued together (a lane owns 4
+  // consecutive columns of each 256-column slab; rows are 16-byte aligned and padded to a multiple of 128 columns).
   float cap = INFINITY;
+  const int ntile = (ncols + 1023) >> 10;
   if (first_chunk && ncols >= 256) {
     float lmin = INFINITY;
-    for (int c0 = 0; c0 < ncols; c0 += 64) {
-      const int c = c0 + lane;
-      lmin = fminf(lmin, c < ncols ? drow[c] : INFINITY);
+    for (int t = 0; t < ntile; ++t) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = (t << 10) + ((u << 6) + lane) * 4;
+        v[u] = *reinterpret_cast<const float4*>(drow + (c < ncols ? c : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = (t << 10) + ((u << 6) + lane) * 4;
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lmin = fminf(lmin, c + q < ncols ? e[q] : INFINITY);
+      }
     }
     // k-th smallest of the 64 minima (distances are >= 0, so the IEEE pattern orders like an integer): bit-wise binary
     // search, one compare + ballot + popcount per bit
@@ -286,13 +300,26 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   if (first_chunk && cap < INFINITY) {
     float2* cand = cand_s[threadIdx.x >> 6];
     int count = 0;
-    for (int c0 = 0; c0 < ncols && count <= kTopkCand; c0 += 64) {
-      const int c = c0 + lane;
-      const float d = c < ncols ? drow[c] : INFINITY;
-      const unsigned long long m = __ballot(d < cap);
-      const int slot = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      if (d < cap && slot < kTopkCand) cand[slot] = make_float2(d, __int_as_float(col_base + c));
-      count += __builtin_popcountll(m);
+    for (int t = 0; t < ntile && count <= kTopkCand; ++t) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = (t << 10) + ((u << 6) + lane) * 4;
+        v[u] = *reinterpret_cast<const float4*>(drow + (c < ncols ? c : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = (t << 10) + ((u << 6) + lane) * 4;
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool in = c + q < ncols && e[q] < cap;
+          const unsigned long long m = __ballot(in);
+          const int slot = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+          if (in && slot < kTopkCand) cand[slot] = make_float2(e[q], __int_as_float(col_base + c + q));
+          count += __builtin_popcountll(m);
+        }
+      }
     }
     if (count <= kTopkCand) {  // count >= k: the bound is attained by k distinct columns
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
