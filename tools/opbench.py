@@ -62,7 +62,7 @@ def main():
     sp = pts[:, :S].contiguous()
     td = torch.zeros((B, Q, 3), device=DEV)
     ti = torch.zeros((B, Q, 3), dtype=torch.long, device=DEV)
-    add("three_nn B32 Q4096 S1024", lambda: ext.three_nn(pts, sp, td, ti), B * Q, "Mq/s")
+    add("three_nn B32 Q4096 S1024", lambda pts=pts, sp=sp, td=td, ti=ti: ext.three_nn(pts, sp, td, ti), B * Q, "Mq/s")
     for (B, C, N, M, K) in ((16, 64, 1024, 512, 32), (32, 64, 4096, 1024, 16), (32, 64, 4096, 1024, 32),
                             (32, 64, 4096, 1024, 128), (32, 64, 1024, 1024, 20), (32, 3, 4096, 1024, 32)):
         src = torch.randn((B, C, N), generator=g).to(DEV)
@@ -81,8 +81,10 @@ def main():
     out = torch.empty((B, C, Q), device=DEV)
     gs = torch.empty((B, C, S), device=DEV)
     nb = B * C * S * 4 + B * Q * 3 * 12 + B * C * Q * 4
-    add("three_interp_fwd C2", lambda: ext.three_interpolate_forward(src, ii, w, out), nb / 1e3, "GB/s")
-    add("three_interp_bwd C2", lambda: ext.three_interpolate_backward(out, ii, w, gs, S), nb / 1e3, "GB/s")
+    add("three_interp_fwd C2", lambda src=src, ii=ii, w=w, out=out: ext.three_interpolate_forward(src, ii, w, out),
+        nb / 1e3, "GB/s")
+    add("three_interp_bwd C2", lambda out=out, ii=ii, w=w, gs=gs, S=S: ext.three_interpolate_backward(out, ii, w, gs, S),
+        nb / 1e3, "GB/s")
     for (B, N, M, C) in ((32, 1024, 1024, 64), (1, 8192, 8192, 256), (1, 16384, 16384, 64)):
         x = torch.randn((B, N, C), generator=g).to(DEV)
         y = torch.randn((B, M, C), generator=g).to(DEV)
