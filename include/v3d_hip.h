@@ -178,6 +178,35 @@ int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, flo
                                 int64_t* sampled_lengths, int64_t* num_sampled, int B, int64_t total, float voxel_size,
                                 int device, void* stream);
 
+/* ---- "next" rows: correspondence selectors downstream of pairwise_distance -----------------------
+ * v3d_mutual_topk_select_f32 replaces vision3d/ops/mutual_topk_select.py:7-60 (B = 1) and :63-133 (batched):
+ * score (B,N,M) fp32; the top-k of every row and of every column (k <= 64, k <= N, k <= M like torch.topk; among equal
+ * scores the lower index wins) are intersected (V3D_SEL_MUTUAL) or united, then filtered by `threshold`
+ * (V3D_SEL_THRESHOLD: score > threshold if V3D_SEL_LARGEST else score < threshold, :48-53) and by the optional
+ * row_masks (B,N) / col_masks (B,M) (bool bytes, :123-126; NULL = none).
+ * Results, either or both: corr_mat (B,N,M) bool bytes, fully written (reduce_result=False, :60/:133); and the
+ * compacted correspondences in torch.nonzero order (ascending batch, row, col): out_batch / out_row / out_col int64 and
+ * out_score fp32 (each may be NULL), at most `capacity` entries written, the true count in *num_out (device scalar;
+ * k*B*min(N,M) bounds it for mutual selection, k*B*(N+M) otherwise).  The score matrix is read twice, nothing of its
+ * size is written unless corr_mat is requested.  No host synchronisation; scratch is stream-ordered (hipMallocAsync).
+ *
+ * v3d_mutual_select_lists_f32 is the same back end for top-k lists that were never a matrix: row_idx/row_val (B,N,k) =
+ * for every row its k best columns, col_idx/col_val (B,M,k) = for every column its k best rows (entries < 0 are
+ * unfilled), e.g. the two v3d_knn_feat_f32 results of (x,y) and (y,x): mutual nearest-neighbour matching of 100k x 100k
+ * descriptors (ops/matching.py:124-151) without the 40 GB matrix.  Values are needed for out_score / threshold only. */
+#define V3D_SEL_LARGEST 1
+#define V3D_SEL_MUTUAL 2
+#define V3D_SEL_THRESHOLD 4
+int v3d_mutual_topk_select_f32(const float* score, const uint8_t* row_masks, const uint8_t* col_masks, int B, int N,
+                               int M, int k, int flags, float threshold, uint8_t* corr_mat, int64_t* out_batch,
+                               int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
+                               int device, void* stream);
+int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, const int64_t* col_idx,
+                                const float* col_val, const uint8_t* row_masks, const uint8_t* col_masks, int B, int N,
+                                int M, int k, int flags, float threshold, uint8_t* corr_mat, int64_t* out_batch,
+                                int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
+                                int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,3 +228,6 @@ def grid_subsample_pack(points, lengths, voxel_size):
     fn.restype = ctypes.c_int64
     m = fn(_p(p), _p(ln), int(ln.shape[0]), ctypes.c_float(voxel_size), _p(out), _p(out_len))
     return out[:m].copy(), out_len
+
+
+from .next_rows import mutual_topk_corr_mat, mutual_topk_select  # noqa: E402,F401  (NumPy)

@@ -87,6 +87,45 @@ def make_reference_fixtures():
                         flat=flat.astype(np.int64), lens=lens)
 
 
+def make_select_fixtures():
+    """ops/mutual_topk_select.py, run on the CPU: its `torch.arange(..).cuda()` calls (:34,:39,:93,:98,:105) are the
+    only GPU dependence, so `Tensor.cuda` is made the identity while the module runs.  Scores are tie-free."""
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        mts = load_by_path("ref_mutual_topk_select", os.path.join(REF, "ops", "mutual_topk_select.py"))
+        rng = np.random.default_rng(20261111)
+        out = {}
+        cases = {"a": (1, 37, 53, 3), "b": (3, 64, 40, 1), "c": (2, 130, 200, 5)}
+        for name, (b, n, m, k) in cases.items():
+            score = rng.standard_normal((b, n, m)).astype(np.float32)
+            rmask = rng.random((b, n)) > 0.2
+            cmask = rng.random((b, m)) > 0.2
+            out[f"{name}_score"], out[f"{name}_k"] = score, np.int64(k)
+            out[f"{name}_rmask"], out[f"{name}_cmask"] = rmask, cmask
+            ts = torch.from_numpy(score)
+            for largest in (True, False):
+                for mutual in (True, False):
+                    for thr in (None, 0.25 if largest else -0.25):
+                        tag = f"{name}_l{int(largest)}_m{int(mutual)}_t{int(thr is not None)}"
+                        corr = mts.batch_mutual_topk_select(ts, k, largest=largest, threshold=thr, mutual=mutual,
+                                                            reduce_result=False)
+                        out[tag] = corr.numpy()
+                        corr = mts.batch_mutual_topk_select(ts, k, row_masks=torch.from_numpy(rmask),
+                                                            col_masks=torch.from_numpy(cmask), largest=largest,
+                                                            threshold=thr, mutual=mutual, reduce_result=False)
+                        out[tag + "_masked"] = corr.numpy()
+            bi, ri, ci, sc = mts.batch_mutual_topk_select(ts, k)
+            out[f"{name}_reduced"] = np.stack([bi.numpy(), ri.numpy(), ci.numpy()])
+            out[f"{name}_reduced_scores"] = sc.numpy()
+        ri, ci, sc = mts.mutual_topk_select(torch.from_numpy(out["a_score"][0]), 3, largest=False, mutual=False)
+        out["a2d_reduced"] = np.stack([ri.numpy(), ci.numpy()])
+        out["a2d_reduced_scores"] = sc.numpy()
+        np.savez_compressed(os.path.join(HERE, "ref_select.npz"), **out)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
 def make_oracle_fixtures():
     rng = np.random.default_rng(7)
     # lattice: 6x6x6 integer grid scaled by 0.25 -> massive distance ties, exactly representable
@@ -120,8 +159,13 @@ def make_oracle_fixtures():
 
 if __name__ == "__main__":
     oracle.build()
-    make_reference_fixtures()
-    make_oracle_fixtures()
+    which = sys.argv[1:] or ["reference", "select", "oracle"]
+    if "reference" in which:
+        make_reference_fixtures()
+    if "select" in which:
+        make_select_fixtures()
+    if "oracle" in which:
+        make_oracle_fixtures()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -29,6 +29,10 @@ __all__ = [
     "radius_count",
     "knn_feat",
     "topk_merge",
+    "radius_search_pack",
+    "grid_subsample_pack",
+    "mutual_topk_select",
+    "mutual_select_lists",
 ]
 
 _FLOATING = {torch.float32: "f32", torch.float64: "f64"}
@@ -351,3 +355,97 @@ def grid_subsample_pack(points, lengths, sampled_points, sampled_lengths, num_sa
         points.data_ptr(), lengths.data_ptr(), sampled_points.data_ptr(), sampled_lengths.data_ptr(),
         num_sampled.data_ptr(), lengths.shape[0], points.shape[0], float(voxel_size), dev, stream)
     _lib.check(rc, "grid_subsample_pack_mode")
+
+
+# --------------------------------------------------------------------------------------------------------
+# Correspondence selectors: pure torch in the reference (ops/mutual_topk_select.py).
+# --------------------------------------------------------------------------------------------------------
+SEL_LARGEST, SEL_MUTUAL, SEL_THRESHOLD = 1, 2, 4
+
+
+def _check_bool(t, name):
+    if t.dtype != torch.bool:
+        raise RuntimeError(f"{name} must be a bool tensor")
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _select_flags(largest, mutual, threshold):
+    return ((SEL_LARGEST if largest else 0) | (SEL_MUTUAL if mutual else 0)
+            | (SEL_THRESHOLD if threshold is not None else 0))
+
+
+def _select_outputs(name, corr_mat, out_batch, out_row, out_col, out_score, num_out, shape):
+    capacity = None
+    for t, n in ((out_batch, "out_batch"), (out_row, "out_row"), (out_col, "out_col")):
+        if t is not None:
+            _check_cuda_contiguous(t, n)
+            _check_long(t, n)
+            capacity = t.numel() if capacity is None else min(capacity, t.numel())
+    if out_score is not None:
+        _check_cuda_contiguous(out_score, "out_score")
+        _check_float(out_score, "out_score")
+        capacity = out_score.numel() if capacity is None else min(capacity, out_score.numel())
+    if num_out is not None:
+        _check_cuda_contiguous(num_out, "num_out")
+        _check_long(num_out, "num_out")
+    if corr_mat is not None:
+        _check_cuda_contiguous(corr_mat, "corr_mat")
+        _check_bool(corr_mat, "corr_mat")
+        if tuple(corr_mat.shape) != tuple(shape):
+            raise RuntimeError(f"{name}: corr_mat must have shape {tuple(shape)}")
+    return capacity or 0
+
+
+def mutual_topk_select(score_mat, k, corr_mat=None, out_batch=None, out_row=None, out_col=None, out_score=None,
+                       num_out=None, row_masks=None, col_masks=None, largest=True, threshold=None, mutual=True):
+    """score_mat (B,N,M) fp32 -> corr_mat (B,N,M) bool and/or compacted (batch,row,col,score) + device count."""
+    _check_cuda_contiguous(score_mat, "score_mat")
+    _check_float(score_mat, "score_mat")
+    B, N, M = score_mat.shape
+    for t, n, shape in ((row_masks, "row_masks", (B, N)), (col_masks, "col_masks", (B, M))):
+        if t is not None:
+            _check_cuda_contiguous(t, n)
+            _check_bool(t, n)
+            if tuple(t.shape) != shape:
+                raise RuntimeError(f"mutual_topk_select: {n} must have shape {shape}")
+    capacity = _select_outputs("mutual_topk_select", corr_mat, out_batch, out_row, out_col, out_score, num_out,
+                               (B, N, M))
+    dev, stream = _where(score_mat)
+    rc = _lib.lib().v3d_mutual_topk_select_f32(
+        score_mat.data_ptr(), _ptr(row_masks), _ptr(col_masks), B, N, M, int(k),
+        _select_flags(largest, mutual, threshold), float(threshold if threshold is not None else 0.0), _ptr(corr_mat),
+        _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev, stream)
+    _lib.check(rc, "mutual_topk_select")
+
+
+def mutual_select_lists(row_idx, row_val, col_idx, col_val, num_cols_total, corr_mat=None, out_batch=None,
+                        out_row=None, out_col=None, out_score=None, num_out=None, row_masks=None, col_masks=None,
+                        largest=False, threshold=None, mutual=True):
+    """row_idx/row_val (B,N,k), col_idx/col_val (B,M,k) top-k lists of both sides -> same outputs as above."""
+    for t, n in ((row_idx, "row_idx"), (col_idx, "col_idx")):
+        _check_cuda_contiguous(t, n)
+        _check_long(t, n)
+    for t, n in ((row_val, "row_val"), (col_val, "col_val")):
+        if t is not None:
+            _check_cuda_contiguous(t, n)
+            _check_float(t, n)
+    B, N, k = row_idx.shape
+    M = col_idx.shape[1]
+    if M != int(num_cols_total) or col_idx.shape[0] != B or col_idx.shape[2] != k:
+        raise RuntimeError("mutual_select_lists: row lists (B,N,k) and column lists (B,M,k) do not match")
+    for t, n in ((row_masks, "row_masks"), (col_masks, "col_masks")):
+        if t is not None:
+            _check_cuda_contiguous(t, n)
+            _check_bool(t, n)
+    capacity = _select_outputs("mutual_select_lists", corr_mat, out_batch, out_row, out_col, out_score, num_out,
+                               (B, N, M))
+    dev, stream = _where(row_idx)
+    rc = _lib.lib().v3d_mutual_select_lists_f32(
+        row_idx.data_ptr(), _ptr(row_val), col_idx.data_ptr(), _ptr(col_val), _ptr(row_masks), _ptr(col_masks), B, N, M,
+        k, _select_flags(largest, mutual, threshold), float(threshold if threshold is not None else 0.0),
+        _ptr(corr_mat), _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev,
+        stream)
+    _lib.check(rc, "mutual_select_lists")

@@ -12,6 +12,8 @@ from .gather import gather
 from .group_gather import group_gather
 from .knn import knn, knn_pack_mode
 from .knn_points import knn_points
+from .matching import extract_correspondences_from_feats
+from .mutual_topk_select import batch_mutual_topk_select, mutual_topk_select
 from .pairwise_distance import pairwise_distance
 from .grid_subsample import grid_subsample_pack_mode
 from .radius_search import radius_count_pack_mode, radius_search_pack_mode
@@ -22,4 +24,5 @@ __all__ = [
     "ball_query", "batch_to_pack", "batch_to_pack_with_lengths", "pack_to_batch", "furthest_point_sample", "gather",
     "group_gather", "knn", "knn_pack_mode", "knn_points", "pairwise_distance", "radius_count_pack_mode",
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
+    "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats",
 ]

@@ -1,0 +1,47 @@
+"""Correspondence extraction from descriptors -- mirrors ``vision3d/ops/matching.py:124-151``.
+
+The reference materialises the (M, N) feature-distance matrix (``pairwise_distance``) and runs ``mutual_topk_select``
+with k = 1 on it.  Here the matrix never exists: the nearest neighbour of every source descriptor among the targets and
+of every target among the sources come from the fused MFMA distance + top-k kernel (``ext.knn_feat``, distance chunks
+stay in the Infinity Cache), and ``ext.mutual_select_lists`` intersects / unites the two lists.  That is what makes
+scene-scale matching (100k x 100k descriptors, BASELINE config 5) possible at all: the matrix would be 40 GB.
+"""
+import torch
+from torch import Tensor
+
+from .. import ext
+
+
+@torch.no_grad()
+def extract_correspondences_from_feats(
+    src_feats: Tensor, tgt_feats: Tensor, mutual: bool = False, return_feat_dist: bool = False, normalized: bool = True
+):
+    """src_feats (M, C), tgt_feats (N, C) -> (src_corr_indices, tgt_corr_indices[, corr_feat_dists]).
+
+    ``corr_feat_dists`` are SQUARED feature distances like the reference's ``pairwise_distance(..., squared=True)``;
+    they come from the exact difference form (sum_c (x_c - y_c)^2), so they agree with the reference's expansion
+    (2 - 2 x.y, or x^2 - 2 x.y + y^2) to its cancellation error, not bit for bit.
+    """
+    if not (src_feats.is_cuda and tgt_feats.is_cuda):
+        raise RuntimeError("extract_correspondences_from_feats: CUDA tensors required (no CPU fallback)")
+    x = src_feats.float().contiguous().unsqueeze(0)
+    y = tgt_feats.float().contiguous().unsqueeze(0)
+    m, n = x.shape[1], y.shape[1]
+    dev = x.device
+    row_d = torch.empty((1, m, 1), device=dev)
+    row_i = torch.empty((1, m, 1), dtype=torch.long, device=dev)
+    col_d = torch.empty((1, n, 1), device=dev)
+    col_i = torch.empty((1, n, 1), dtype=torch.long, device=dev)
+    ext.knn_feat(x, y, row_d, row_i, 1)
+    ext.knn_feat(y, x, col_d, col_i, 1)
+    bound = max(min(m, n) if mutual else m + n, 1)
+    idx = torch.empty((2, bound), dtype=torch.long, device=dev)
+    dist = torch.empty((bound,), device=dev)
+    count = torch.zeros((), dtype=torch.long, device=dev)
+    ext.mutual_select_lists(row_i, row_d, col_i, col_d, n, out_row=idx[0], out_col=idx[1], out_score=dist,
+                            num_out=count, largest=False, mutual=mutual)
+    c = int(count.item())
+    if return_feat_dist:
+        d = dist[:c]
+        return idx[0, :c], idx[1, :c], (d * d).to(src_feats.dtype)
+    return idx[0, :c], idx[1, :c]
