@@ -207,6 +207,45 @@ int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, co
                                 int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
                                 int device, void* stream);
 
+/* ---- "next" rows: PACK-mode row gathers (features row-major (N,C), neighbour table (M,K) int64,
+ * entries equal to N -- or anything outside [0,N) -- mean "no neighbour" and read as a row of zeros, which is what the
+ * reference obtains by concatenating a zero row: cat(feats, zeros(1,C)) + index_select) ------------------------------
+ *
+ * v3d_index_select_rows replaces vision3d/ops/index_select.py:4-33 for dim = 0 on a 2-D source of any element type:
+ * targets[l,:] = sources[indices[l * index_stride], :], L rows of row_bytes bytes.  index_stride = K with L = M reads
+ * only the first column of an (M,K) table = ops/nearest_interpolate.py:6-20.
+ * v3d_local_maxpool_pack_f32 replaces ops/pooling.py:6-19: pooled[m,c] = max_k padded[idx[m,k],c]; the (M,K,C)
+ * intermediate is never written.  argk (optional, (M,C) bytes, K <= 255) = first k attaining the maximum, for backward.
+ * v3d_knn_interp_weights_pack_f32 + v3d_rows_weighted_sum_f32 replace ops/knn_interpolate.py:43-76: weights (M,k_used)
+ * = mask/(|q-s|^2+eps) normalised by (sum+eps); out[m,:] = sum_k weights[m,k] * padded[idx[m,k],:] (k ascending, one
+ * rounding per multiply and per add).  K = row length of the table, k_used <= K = columns that take part.
+ * v3d_global_avgpool_pack_f32 replaces ops/pooling.py:22-39 (the reference loops over clouds with .item() syncs).
+ * C must be a multiple of 4 and the fp32 buffers 16-byte aligned for the *_f32 entry points. */
+int v3d_index_select_rows(const void* sources, const int64_t* indices, int64_t index_stride, void* targets, int64_t L,
+                          int64_t N, int64_t row_bytes, int device, void* stream);
+int v3d_local_maxpool_pack_f32(const float* feats, const int64_t* neighbor_indices, float* pooled, uint8_t* argk,
+                               int64_t M, int64_t N, int K, int C, int device, void* stream);
+int v3d_knn_interp_weights_pack_f32(const float* q_points, const float* s_points, const int64_t* neighbor_indices,
+                                    float* weights, int64_t M, int64_t N, int K, int k_used, float eps, int device,
+                                    void* stream);
+int v3d_rows_weighted_sum_f32(const float* feats, const int64_t* neighbor_indices, const float* weights, float* out,
+                              int64_t M, int64_t N, int K, int k_used, int C, int device, void* stream);
+int v3d_global_avgpool_pack_f32(const float* feats, const int64_t* lengths, float* pooled, int B, int C, int device,
+                                void* stream);
+/* Backward of the three gathers above, atomic-free (the reference's autograd scatters with float atomics).  The table is
+ * inverted ONCE into a CSR over sources (v3d_rows_csr_build: stable sort of (source, position); `csr` = caller buffer of
+ * v3d_rows_csr_bytes(N, L) bytes, 256-B aligned, L = number of table entries) and can be kept for every layer that
+ * shares the table.  v3d_rows_scatter_f32 then writes source_grads (N,C) in full, each row summed in ascending table
+ * position (bit-reproducible):
+ *   mode 0: target_grads (L,C), optional weights (L)                -- index_select backward
+ *   mode 1: target_grads (L/K, C), weights (L/K, k_used)            -- weighted-sum backward w.r.t. the features
+ *   mode 2: target_grads (L/K, C), argk (L/K, C) from the forward   -- max-pool backward */
+size_t v3d_rows_csr_bytes(int64_t N, int64_t L);
+int v3d_rows_csr_build(const int64_t* indices, int64_t L, int64_t N, void* csr, size_t csr_bytes, int device,
+                       void* stream);
+int v3d_rows_scatter_f32(const float* target_grads, const void* csr, const float* weights, const uint8_t* argk, int mode,
+                         float* source_grads, int64_t L, int64_t N, int K, int k_used, int C, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,3 +41,101 @@ def mutual_topk_select(score_mat, k, **kw):
     corr = mutual_topk_corr_mat(s, k, **kw)
     b, r, c = np.nonzero(corr)
     return b.astype(np.int64), r.astype(np.int64), c.astype(np.int64), s[b, r, c]
+
+
+# ---- rank 3: pack-mode row gathers ------------------------------------------------------------------------------
+def _padded(feats):
+    feats = np.asarray(feats)
+    return np.concatenate([feats, np.zeros_like(feats[:1])], axis=0)  # pooling.py:16, knn_interpolate.py:65-66
+
+
+def _clamp(indices, n):
+    idx = np.asarray(indices, dtype=np.int64)
+    return np.where((idx >= 0) & (idx < n), idx, n)
+
+
+def index_select_rows(feats, indices):
+    """index_select(cat(feats, zeros), indices, dim=0) (index_select.py:25-33): (..., C)."""
+    feats = np.asarray(feats)
+    return _padded(feats)[_clamp(indices, feats.shape[0])]
+
+
+def local_maxpool_pack(feats, neighbor_indices):
+    """pooling.py:16-18 -> (pooled (M,C), argk (M,C) = first maximising column)."""
+    g = index_select_rows(np.asarray(feats, dtype=np.float32), neighbor_indices)  # (M,K,C)
+    return g.max(axis=1), g.argmax(axis=1).astype(np.uint8)
+
+
+def nearest_interpolate_pack(inputs, neighbor_indices):
+    """nearest_interpolate.py:18-20."""
+    return index_select_rows(inputs, np.asarray(neighbor_indices)[:, 0])
+
+
+def knn_interp_weights_pack(q_points, s_points, neighbor_indices, k=None, eps=1e-8):
+    """knn_interpolate.py:67-73 in float32, one rounding per operation, sums in ascending k."""
+    q = np.asarray(q_points, dtype=np.float32)
+    s = _padded(np.asarray(s_points, dtype=np.float32))
+    idx = np.asarray(neighbor_indices, dtype=np.int64)
+    idx = idx if k is None else idx[:, :k]
+    n = s.shape[0] - 1
+    ci = _clamp(idx, n)
+    d = q[:, None, :] - s[ci]
+    sq = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    eps = np.float32(eps)
+    w = np.where(ci != n, np.float32(1) / (sq + eps), np.float32(0)).astype(np.float32)
+    total = np.zeros(w.shape[0], dtype=np.float32)
+    for j in range(w.shape[1]):
+        total = total + w[:, j]
+    return (w / (total + eps)[:, None]).astype(np.float32)
+
+
+def rows_weighted_sum(feats, neighbor_indices, weights):
+    """knn_interpolate.py:74-75: sum_k w[m,k] * padded[idx[m,k],:], ascending k, float32."""
+    feats = np.asarray(feats, dtype=np.float32)
+    w = np.asarray(weights, dtype=np.float32)
+    idx = np.asarray(neighbor_indices, dtype=np.int64)[:, : w.shape[1]]
+    g = index_select_rows(feats, idx)
+    acc = np.zeros((idx.shape[0], feats.shape[1]), dtype=np.float32)
+    for j in range(w.shape[1]):
+        acc = acc + g[:, j, :] * w[:, j : j + 1]
+    return acc
+
+
+def knn_interpolate_pack(q_points, s_points, s_feats, neighbor_indices, k=None, eps=1e-8):
+    return rows_weighted_sum(s_feats, neighbor_indices, knn_interp_weights_pack(q_points, s_points, neighbor_indices, k, eps))
+
+
+def global_avgpool_pack(feats, lengths):
+    """pooling.py:22-39 (float64 accumulation: the order of torch.mean's sum is not part of the contract)."""
+    feats = np.asarray(feats, dtype=np.float32)
+    out, start = [], 0
+    for n in np.asarray(lengths, dtype=np.int64):
+        out.append(feats[start : start + n].astype(np.float64).mean(axis=0))
+        start += n
+    return np.stack(out).astype(np.float32)
+
+
+def rows_scatter(target_grads, neighbor_indices, num_sources, mode=0, weights=None, argk=None):
+    """Backward of the three gathers w.r.t. the features: every source row summed in ascending table position
+    (np.add.at applies its updates sequentially, i.e. in exactly that order), float32."""
+    idx = np.asarray(neighbor_indices, dtype=np.int64)
+    g = np.asarray(target_grads, dtype=np.float32)
+    n, c = int(num_sources), g.shape[-1]
+    out = np.zeros((n + 1, c), dtype=np.float32)
+    if mode == 0:
+        contrib = g.reshape(-1, c)
+        if weights is not None:
+            contrib = contrib * np.asarray(weights, dtype=np.float32).reshape(-1, 1)
+        np.add.at(out, _clamp(idx, n).reshape(-1), contrib)
+    elif mode == 1:
+        w = np.asarray(weights, dtype=np.float32)
+        ku = w.shape[1]
+        contrib = g[:, None, :] * w[:, :, None]
+        np.add.at(out, _clamp(idx[:, :ku], n).reshape(-1), contrib.reshape(-1, c))
+    else:
+        m, k = idx.shape
+        sel = np.asarray(argk)[:, None, :] == np.arange(k, dtype=np.int64)[None, :, None]  # (M,K,C)
+        contrib = np.where(sel, g[:, None, :], np.float32(0))
+        # adding an exact 0.0 leaves a float32 sum unchanged, so masked entries may take part in the ordered sum
+        np.add.at(out, _clamp(idx, n).reshape(-1), contrib.reshape(-1, c))
+    return out[:n]

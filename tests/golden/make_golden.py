@@ -126,6 +126,52 @@ def make_select_fixtures():
         torch.Tensor.cuda = orig_cuda
 
 
+def make_pack_ops_fixtures():
+    """ops/index_select.py, ops/pooling.py, ops/nearest_interpolate.py (pure torch) run on the CPU.  They import each other
+    relatively, so they are loaded as submodules of an empty synthetic parent package whose __path__ is the reference's ops
+    directory (the real ops/__init__.py pulls in pykeops and the unbuilt extension).  ops/knn_interpolate.py imports
+    ops/knn.py -> pykeops at module level and therefore stays unpinned."""
+    import types
+
+    parent = types.ModuleType("v3dref_ops")
+    parent.__path__ = [os.path.join(REF, "ops")]
+    sys.modules["v3dref_ops"] = parent
+    try:
+        import importlib
+
+        pooling = importlib.import_module("v3dref_ops.pooling")
+        nearest = importlib.import_module("v3dref_ops.nearest_interpolate")
+        isel = importlib.import_module("v3dref_ops.index_select")
+        rng = np.random.default_rng(20261112)
+        n, m, k, c = 300, 170, 9, 24
+        feats = rng.standard_normal((n, c)).astype(np.float32)
+        table = rng.integers(0, n + 1, size=(m, k)).astype(np.int64)  # value n = "no neighbour"
+        table[5] = n  # a query without any neighbour
+        lengths = np.asarray([120, 0 + 80, 100], dtype=np.int64)
+        tf, tt = torch.from_numpy(feats), torch.from_numpy(table)
+        padded = torch.cat([tf, torch.zeros_like(tf[:1])], 0)
+        out = {
+            "feats": feats, "table": table, "lengths": lengths,
+            "index_select": isel.index_select(padded, tt, dim=0).numpy(),
+            "maxpool": pooling.local_maxpool_pack_mode(tf, tt).numpy(),
+            "avgpool": pooling.global_avgpool_pack_mode(tf, torch.from_numpy(lengths)).numpy(),
+            "nearest": nearest.nearest_interpolate_pack_mode(tf, tt).numpy(),
+        }
+        # autograd of the reference formulation = the backward the native kernels must reproduce (to rounding)
+        tf2 = tf.clone().requires_grad_(True)
+        up = torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32))
+        pooling.local_maxpool_pack_mode(tf2, tt).backward(up)
+        out["maxpool_upstream"], out["maxpool_grad"] = up.numpy(), tf2.grad.numpy()
+        tf3 = tf.clone().requires_grad_(True)
+        up3 = torch.from_numpy(rng.standard_normal((m, k, c)).astype(np.float32))
+        isel.index_select(torch.cat([tf3, torch.zeros_like(tf3[:1])], 0), tt, dim=0).backward(up3)
+        out["index_select_upstream"], out["index_select_grad"] = up3.numpy(), tf3.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, "ref_pack_ops.npz"), **out)
+    finally:
+        for name in [k_ for k_ in sys.modules if k_.startswith("v3dref_ops")]:
+            del sys.modules[name]
+
+
 def make_oracle_fixtures():
     rng = np.random.default_rng(7)
     # lattice: 6x6x6 integer grid scaled by 0.25 -> massive distance ties, exactly representable
@@ -159,7 +205,9 @@ def make_oracle_fixtures():
 
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["reference", "select", "oracle"]
+    which = sys.argv[1:] or ["reference", "select", "pack", "oracle"]
+    if "pack" in which:
+        make_pack_ops_fixtures()
     if "reference" in which:
         make_reference_fixtures()
     if "select" in which:

@@ -117,3 +117,131 @@ def test_mutual_select_lists_matches_matrix_route(ext, oracle_mod):
         assert np.abs(N_(fd) - d[wr, wc]).max() <= 2e-5
         r2, c2 = ops.extract_correspondences_from_feats(T(x), T(y), mutual=mutual)
         assert np.array_equal(N_(r2), wr) and np.array_equal(N_(c2), wc)
+
+
+# ------------------------------------------------------------------------------------------------------
+# rank 3: pack-mode row gathers
+# ------------------------------------------------------------------------------------------------------
+def _table(rng, m, k, n, none_frac=0.2):
+    t = rng.integers(0, n, size=(m, k)).astype(np.int64)
+    t[rng.random((m, k)) < none_frac] = n
+    if m > 3:
+        t[3] = n
+    return t
+
+
+def test_pack_gathers_vs_reference_fixture(ext, golden):
+    from vision3d_amd import ops
+
+    g = golden("ref_pack_ops.npz")
+    feats, table = T(g["feats"]), T(g["table"])
+    padded = torch.cat([feats, torch.zeros_like(feats[:1])], 0)
+    assert np.array_equal(N_(ops.index_select(padded, table, dim=0)), g["index_select"])
+    assert np.array_equal(N_(ops.index_select(feats, table, dim=0)), g["index_select"])  # the zero row is implicit
+    assert np.array_equal(N_(ops.local_maxpool_pack_mode(feats, table)), g["maxpool"])
+    assert np.array_equal(N_(ops.nearest_interpolate_pack_mode(feats, table)), g["nearest"])
+    got = ops.global_avgpool_pack_mode(feats, T(g["lengths"]))
+    assert np.abs(N_(got) - g["avgpool"]).max() <= 1e-5 * np.abs(g["feats"]).max()
+    # backward against the reference's autograd results (1e-5 of the summed magnitude: its order is not ours)
+    scale = np.abs(g["index_select_upstream"]).max() * g["table"].shape[1]
+    f = feats.clone().requires_grad_(True)
+    ops.index_select(f, table, dim=0).backward(T(g["index_select_upstream"]))
+    assert np.abs(N_(f.grad) - g["index_select_grad"]).max() <= 1e-5 * scale
+    f = feats.clone().requires_grad_(True)
+    ops.local_maxpool_pack_mode(f, table).backward(T(g["maxpool_upstream"]))
+    assert np.abs(N_(f.grad) - g["maxpool_grad"]).max() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("n,m,k,c", [(1, 1, 1, 4), (100, 77, 5, 4), (1000, 513, 38, 64), (5000, 3000, 16, 128),
+                                     (300, 2000, 7, 20), (2000, 100, 64, 256), (700, 900, 3, 1028)])
+def test_pack_gathers_vs_oracle_bit_exact(ext, oracle_mod, n, m, k, c):
+    rng = np.random.default_rng(n + m + k + c)
+    feats = rng.standard_normal((n, c)).astype(np.float32)
+    feats[rng.random((n, c)) < 0.05] = 0.0  # ties against the implicit zero row
+    table = _table(rng, m, k, n)
+    tf, tt = T(feats), T(table)
+    # gather (16-byte path) and its first-column form
+    out = torch.empty((m, k, c), device=DEV)
+    ext.index_select_rows(tf, tt, out)
+    assert np.array_equal(N_(out), oracle_mod.index_select_rows(feats, table))
+    out1 = torch.empty((m, c), device=DEV)
+    ext.index_select_rows(tf, tt, out1, index_stride=k)
+    assert np.array_equal(N_(out1), oracle_mod.nearest_interpolate_pack(feats, table))
+    # max pool + argk
+    pooled = torch.empty((m, c), device=DEV)
+    argk = torch.empty((m, c), dtype=torch.uint8, device=DEV)
+    ext.local_maxpool_pack(tf, tt, pooled, argk)
+    wp, wa = oracle_mod.local_maxpool_pack(feats, table)
+    assert np.array_equal(N_(pooled), wp) and np.array_equal(N_(argk), wa)
+    # inverse-distance weights + weighted sum (bit-identical: same operation order, no contraction)
+    s_pts = rng.random((n, 3), dtype=np.float32)
+    q_pts = rng.random((m, 3), dtype=np.float32)
+    ku = max(1, k - 2)
+    w = torch.empty((m, ku), device=DEV)
+    ext.knn_interp_weights_pack(T(q_pts), T(s_pts), tt, w, 1e-8)
+    ww = oracle_mod.knn_interp_weights_pack(q_pts, s_pts, table, k=ku, eps=1e-8)
+    assert np.array_equal(N_(w), ww)
+    o = torch.empty((m, c), device=DEV)
+    ext.rows_weighted_sum(tf, tt, w, o)
+    assert np.array_equal(N_(o), oracle_mod.rows_weighted_sum(feats, table, ww))
+    # the three backward modes: equal to the sequential loop bit for bit
+    csr = ext.rows_csr_build(tt, n)
+    up = rng.standard_normal((m, k, c)).astype(np.float32)
+    gs = torch.empty((n, c), device=DEV)
+    ext.rows_scatter(T(up).view(m * k, c), csr, gs, (m * k, 1), mode=0)
+    assert np.array_equal(N_(gs), oracle_mod.rows_scatter(up, table, n, mode=0))
+    up2 = rng.standard_normal((m, c)).astype(np.float32)
+    ext.rows_scatter(T(up2), csr, gs, (m, k), mode=1, weights=w)
+    assert np.array_equal(N_(gs), oracle_mod.rows_scatter(up2, table, n, mode=1, weights=ww))
+    ext.rows_scatter(T(up2), csr, gs, (m, k), mode=2, argk=argk)
+    assert np.array_equal(N_(gs), oracle_mod.rows_scatter(up2, table, n, mode=2, argk=wa))
+
+
+@pytest.mark.parametrize("dtype,c", [(np.int64, 3), (np.float64, 5), (np.int32, 7), (np.uint8, 13), (np.int16, 6),
+                                     (np.float32, 3)])
+def test_index_select_rows_any_dtype_and_row_width(ext, oracle_mod, dtype, c):
+    rng = np.random.default_rng(c)
+    src = (rng.standard_normal((200, c)) * 50).astype(dtype)
+    table = _table(rng, 150, 4, 200)
+    out = torch.empty((150, 4, c), dtype=T(src).dtype, device=DEV)
+    ext.index_select_rows(T(src), T(table), out)
+    assert np.array_equal(N_(out), oracle_mod.index_select_rows(src, table))
+
+
+def test_pack_ops_wrappers_and_autograd(ext, oracle_mod):
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(11)
+    n, m, k, c = 400, 350, 12, 32
+    feats = rng.standard_normal((n, c)).astype(np.float32)
+    table = _table(rng, m, k, n)
+    s_pts, q_pts = rng.random((n, 3), dtype=np.float32), rng.random((m, 3), dtype=np.float32)
+    up = rng.standard_normal((m, c)).astype(np.float32)
+    f = T(feats).requires_grad_(True)
+    out = ops.knn_interpolate_pack_mode(T(q_pts), T(s_pts), f, T(table), k=5)
+    assert np.array_equal(N_(out), oracle_mod.knn_interpolate_pack(q_pts, s_pts, feats, table, k=5))
+    out.backward(T(up))
+    ww = oracle_mod.knn_interp_weights_pack(q_pts, s_pts, table, k=5)
+    assert np.array_equal(N_(f.grad), oracle_mod.rows_scatter(up, table, n, mode=1, weights=ww))
+    # the CSR is cached on the table tensor and reused by every operator that shares the table
+    tt = T(table)
+    f2 = T(feats).requires_grad_(True)
+    ops.local_maxpool_pack_mode(f2, tt).sum().backward()
+    first = tt._v3d_csr[1]
+    f3 = T(feats).requires_grad_(True)
+    ops.local_maxpool_pack_mode(f3, tt).sum().backward()
+    assert tt._v3d_csr[1] is first and torch.equal(f2.grad, f3.grad)
+    # global average pooling: mean per cloud, gradient = upstream / length on every row of the cloud
+    lengths = torch.tensor([100, 250, 50], device=DEV)
+    f4 = T(feats).requires_grad_(True)
+    pooled = ops.global_avgpool_pack_mode(f4, lengths)
+    want = oracle_mod.global_avgpool_pack(feats, [100, 250, 50])
+    assert np.abs(N_(pooled) - want).max() <= 1e-5 * np.abs(feats).max()
+    pooled.sum().backward()
+    assert torch.allclose(f4.grad[:100], torch.full((100, c), 1 / 100, device=DEV))
+    # generic index_select semantics outside the native layout stay the reference's
+    x = T(rng.standard_normal((4, 6, 5)).astype(np.float32))
+    idx = torch.tensor([[0, 2], [5, 1]], device=DEV)
+    assert ops.index_select(x, idx, dim=1).shape == (4, 2, 2, 5)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        ops.local_maxpool_pack_mode(torch.zeros(4, 4), torch.zeros(2, 2, dtype=torch.long))

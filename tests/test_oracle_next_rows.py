@@ -36,3 +36,43 @@ def test_mutual_topk_oracle_tie_rule_lower_index_first(oracle_mod):
     want = np.zeros((1, 4, 5), dtype=bool)
     want[0, :2, :2] = True
     assert np.array_equal(corr, want)
+
+
+# ---- rank 3: pack-mode row gathers ---------------------------------------------------------------------------
+def test_pack_gather_oracle_matches_reference_fixture(oracle_mod, golden):
+    g = golden("ref_pack_ops.npz")
+    feats, table = g["feats"], g["table"]
+    assert np.array_equal(oracle_mod.index_select_rows(feats, table), g["index_select"])
+    pooled, argk = oracle_mod.local_maxpool_pack(feats, table)
+    assert np.array_equal(pooled, g["maxpool"])
+    assert np.array_equal(oracle_mod.nearest_interpolate_pack(feats, table), g["nearest"])
+    # torch.mean's summation order is not part of the contract: 1e-5 of the operand scale
+    assert np.abs(oracle_mod.global_avgpool_pack(feats, g["lengths"]) - g["avgpool"]).max() <= 1e-5 * np.abs(feats).max()
+    # backward: torch autograd of the reference formulation (float atomics / unordered on GPU, sequential on CPU)
+    got = oracle_mod.rows_scatter(g["index_select_upstream"], table, feats.shape[0], mode=0)
+    scale = np.abs(g["index_select_upstream"]).max() * table.shape[1]
+    assert np.abs(got - g["index_select_grad"]).max() <= 1e-5 * scale
+    got = oracle_mod.rows_scatter(g["maxpool_upstream"], table, feats.shape[0], mode=2, argk=argk)
+    assert np.abs(got - g["maxpool_grad"]).max() <= 1e-5 * scale
+
+
+def test_knn_interpolate_oracle_properties(oracle_mod):
+    """ops/knn_interpolate.py cannot be imported (pykeops at module level): parity unpinned, checked by properties."""
+    rng = np.random.default_rng(3)
+    s = rng.random((50, 3), dtype=np.float32)
+    q = rng.random((40, 3), dtype=np.float32)
+    feats = rng.standard_normal((50, 8)).astype(np.float32)
+    table = rng.integers(0, 51, size=(40, 6)).astype(np.int64)
+    table[0] = 50
+    w = oracle_mod.knn_interp_weights_pack(q, s, table, k=4)
+    assert w.shape == (40, 4) and np.all(w[0] == 0) and np.all(w[table[:, :4] == 50] == 0)
+    has = (table[:, :4] != 50).any(axis=1)
+    assert np.allclose(w[has].sum(axis=1), 1.0, atol=1e-5)
+    const = np.ones((50, 8), dtype=np.float32) * 3
+    out = oracle_mod.knn_interpolate_pack(q, s, const, table, k=4)
+    assert np.allclose(out[has], 3.0, atol=1e-4) and np.all(out[0] == 0)
+    # a query sitting on a support point reproduces that point's features
+    q2 = s[:5].copy()
+    t2 = np.stack([np.arange(5), (np.arange(5) + 7) % 50], axis=1).astype(np.int64)
+    out = oracle_mod.knn_interpolate_pack(q2, s, feats, t2)
+    assert np.allclose(out, feats[:5], atol=1e-4)

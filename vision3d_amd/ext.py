@@ -33,6 +33,13 @@ __all__ = [
     "grid_subsample_pack",
     "mutual_topk_select",
     "mutual_select_lists",
+    "index_select_rows",
+    "local_maxpool_pack",
+    "knn_interp_weights_pack",
+    "rows_weighted_sum",
+    "global_avgpool_pack",
+    "rows_csr_build",
+    "rows_scatter",
 ]
 
 _FLOATING = {torch.float32: "f32", torch.float64: "f64"}
@@ -449,3 +456,110 @@ def mutual_select_lists(row_idx, row_val, col_idx, col_val, num_cols_total, corr
         _ptr(corr_mat), _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev,
         stream)
     _lib.check(rc, "mutual_select_lists")
+
+
+# --------------------------------------------------------------------------------------------------------
+# PACK-mode row gathers: pure torch in the reference (ops/index_select.py, ops/pooling.py,
+# ops/nearest_interpolate.py, ops/knn_interpolate.py).  Features (N,C) row-major, tables (M,K) int64, index N = none.
+# --------------------------------------------------------------------------------------------------------
+def index_select_rows(sources, indices, targets, index_stride=1):
+    """targets[l,:] = sources[indices.view(-1)[l*index_stride],:] (zeros outside [0,N)); any dtype, 2-D sources."""
+    _check_cuda_contiguous(sources, "sources")
+    _check_cuda_contiguous(indices, "indices")
+    _check_cuda_contiguous(targets, "targets")
+    _check_long(indices, "indices")
+    _same_dtype("index_select_rows", sources, targets)
+    N, row_bytes = sources.shape[0], sources.shape[1] * sources.element_size()
+    L = targets.numel() // max(sources.shape[1], 1)
+    if indices.numel() < (L - 1) * int(index_stride) + 1 and L > 0:
+        raise RuntimeError("index_select_rows: indices too short for the requested rows")
+    dev, stream = _where(sources)
+    _lib.check(_lib.lib().v3d_index_select_rows(sources.data_ptr(), indices.data_ptr(), int(index_stride),
+                                                targets.data_ptr(), L, N, row_bytes, dev, stream), "index_select_rows")
+
+
+def local_maxpool_pack(feats, neighbor_indices, pooled, argk=None):
+    """feats (N,C) fp32, neighbor_indices (M,K) -> pooled (M,C); argk (M,C) uint8 = first maximising column."""
+    for t, n in ((feats, "feats"), (pooled, "pooled")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(neighbor_indices, "neighbor_indices")
+    _check_long(neighbor_indices, "neighbor_indices")
+    if argk is not None:
+        _check_cuda_contiguous(argk, "argk")
+        if argk.dtype != torch.uint8:
+            raise RuntimeError("argk must be a byte tensor")
+    M, K = neighbor_indices.shape
+    N, C = feats.shape
+    dev, stream = _where(feats)
+    _lib.check(_lib.lib().v3d_local_maxpool_pack_f32(feats.data_ptr(), neighbor_indices.data_ptr(), pooled.data_ptr(),
+                                                     _ptr(argk), M, N, K, C, dev, stream), "local_maxpool_pack_mode")
+
+
+def knn_interp_weights_pack(q_points, s_points, neighbor_indices, weights, eps):
+    """q (M,3), s (N,3) fp32, table (M,K) -> weights (M,k_used), k_used = weights.shape[1] <= K."""
+    for t, n in ((q_points, "q_points"), (s_points, "s_points"), (weights, "weights")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(neighbor_indices, "neighbor_indices")
+    _check_long(neighbor_indices, "neighbor_indices")
+    M, K = neighbor_indices.shape
+    dev, stream = _where(q_points)
+    _lib.check(_lib.lib().v3d_knn_interp_weights_pack_f32(
+        q_points.data_ptr(), s_points.data_ptr(), neighbor_indices.data_ptr(), weights.data_ptr(), M,
+        s_points.shape[0], K, weights.shape[1], float(eps), dev, stream), "knn_interpolate_pack_mode")
+
+
+def rows_weighted_sum(feats, neighbor_indices, weights, out):
+    """out[m,:] = sum_k weights[m,k] * padded_feats[neighbor_indices[m,k],:], k < weights.shape[1]."""
+    for t, n in ((feats, "feats"), (weights, "weights"), (out, "out")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(neighbor_indices, "neighbor_indices")
+    _check_long(neighbor_indices, "neighbor_indices")
+    M, K = neighbor_indices.shape
+    N, C = feats.shape
+    dev, stream = _where(feats)
+    _lib.check(_lib.lib().v3d_rows_weighted_sum_f32(feats.data_ptr(), neighbor_indices.data_ptr(), weights.data_ptr(),
+                                                    out.data_ptr(), M, N, K, weights.shape[1], C, dev, stream),
+               "rows_weighted_sum")
+
+
+def global_avgpool_pack(feats, lengths, pooled):
+    """feats (N,C) fp32, lengths (B,) int64 on the device -> pooled (B,C)."""
+    for t, n in ((feats, "feats"), (pooled, "pooled")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(lengths, "lengths")
+    _check_long(lengths, "lengths")
+    dev, stream = _where(feats)
+    _lib.check(_lib.lib().v3d_global_avgpool_pack_f32(feats.data_ptr(), lengths.data_ptr(), pooled.data_ptr(),
+                                                      lengths.shape[0], feats.shape[1], dev, stream),
+               "global_avgpool_pack_mode")
+
+
+def rows_csr_build(indices, num_sources):
+    """Inverse (CSR over sources) of a neighbour table; returns the opaque device buffer the scatter calls take."""
+    _check_cuda_contiguous(indices, "indices")
+    _check_long(indices, "indices")
+    L, N = indices.numel(), int(num_sources)
+    nbytes = _lib.lib().v3d_rows_csr_bytes(N, L)
+    csr = _workspace(nbytes, indices)
+    dev, stream = _where(indices)
+    _lib.check(_lib.lib().v3d_rows_csr_build(indices.data_ptr(), L, N, csr.data_ptr(), csr.numel(), dev, stream),
+               "rows_csr_build")
+    return csr
+
+
+def rows_scatter(target_grads, csr, source_grads, table_shape, mode=0, weights=None, argk=None):
+    """Atomic-free backward of the row gathers; table_shape = (M, K) of the table the csr was built from."""
+    for t, n in ((target_grads, "target_grads"), (source_grads, "source_grads")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    M, K = table_shape
+    N, C = source_grads.shape
+    k_used = weights.shape[1] if (weights is not None and mode == 1) else K
+    dev, stream = _where(target_grads)
+    _lib.check(_lib.lib().v3d_rows_scatter_f32(target_grads.data_ptr(), csr.data_ptr(), _ptr(weights), _ptr(argk),
+                                               int(mode), source_grads.data_ptr(), M * K, N, K, k_used, C, dev, stream),
+               "rows_scatter")

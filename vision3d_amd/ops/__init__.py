@@ -14,6 +14,8 @@ from .knn import knn, knn_pack_mode
 from .knn_points import knn_points
 from .matching import extract_correspondences_from_feats
 from .mutual_topk_select import batch_mutual_topk_select, mutual_topk_select
+from .pack_gather import (global_avgpool_pack_mode, index_select, knn_interpolate_pack_mode,
+                          local_maxpool_pack_mode, nearest_interpolate_pack_mode)
 from .pairwise_distance import pairwise_distance
 from .grid_subsample import grid_subsample_pack_mode
 from .radius_search import radius_count_pack_mode, radius_search_pack_mode
@@ -25,4 +27,6 @@ __all__ = [
     "group_gather", "knn", "knn_pack_mode", "knn_points", "pairwise_distance", "radius_count_pack_mode",
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats",
+    "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
+    "knn_interpolate_pack_mode",
 ]
