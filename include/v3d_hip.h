@@ -246,6 +246,19 @@ int v3d_rows_csr_build(const int64_t* indices, int64_t L, int64_t N, void* csr, 
 int v3d_rows_scatter_f32(const float* target_grads, const void* csr, const float* weights, const uint8_t* argk, int mode,
                          float* source_grads, int64_t L, int64_t N, int K, int k_used, int C, int device, void* stream);
 
+/* ---- "next" rows: fused grouping of the batch-mode layers ----------------------------------------
+ * v3d_sa_group_f32 writes the input of a set-abstraction MLP in one pass (vision3d/layers/pointnet2.py:44-47:
+ * group_gather(points), subtract the centroid, group_gather(feats), torch.cat): q_points (B,3,M), s_points (B,3,N),
+ * s_feats (B,C,N) (NULL with C = 0), indices (B,M,K) -> grouped (B,C+3,M,K) with channels [0,C) = s_feats[b,c,idx] and
+ * [C,C+3) = s_points[b,c,idx] - q_points[b,c,m].
+ * v3d_edge_group_f32 writes the input of an EdgeConv MLP (layers/edge_conv.py:59-61): q_feats (B,C,M), s_feats (B,C,N),
+ * indices (B,M,K) -> grouped (B,2C,M,K) with channels [0,C) = q_feats[b,c,m] and [C,2C) = s_feats[b,c,idx] -
+ * q_feats[b,c,m].  Same single fp32 subtraction as the reference: bit-identical.  Indices outside [0,N) read as 0. */
+int v3d_sa_group_f32(const float* q_points, const float* s_points, const float* s_feats, const int64_t* indices,
+                     float* grouped, int B, int C, int N, int M, int K, int device, void* stream);
+int v3d_edge_group_f32(const float* q_feats, const float* s_feats, const int64_t* indices, float* grouped, int B, int C,
+                       int N, int M, int K, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,3 +139,28 @@ def rows_scatter(target_grads, neighbor_indices, num_sources, mode=0, weights=No
         # adding an exact 0.0 leaves a float32 sum unchanged, so masked entries may take part in the ordered sum
         np.add.at(out, _clamp(idx, n).reshape(-1), contrib.reshape(-1, c))
     return out[:n]
+
+
+# ---- rank 4: fused grouping of the batch-mode layers ------------------------------------------------------------
+def _group_gather(src, idx):
+    """out[b,c,m,k] = src[b,c,idx[b,m,k]] (group_gather_cuda.cuh:29-32)."""
+    src, idx = np.asarray(src), np.asarray(idx, dtype=np.int64)
+    b = np.arange(src.shape[0])[:, None, None, None]
+    c = np.arange(src.shape[1])[None, :, None, None]
+    return src[b, c, idx[:, None, :, :]]
+
+
+def sa_group(q_points, s_points, s_feats, neighbor_indices):
+    """layers/pointnet2.py:44-47: cat([group_gather(feats), group_gather(points) - q.unsqueeze(3)], dim=1)."""
+    q = np.asarray(q_points, dtype=np.float32)
+    offsets = _group_gather(np.asarray(s_points, dtype=np.float32), neighbor_indices) - q[:, :, :, None]
+    if s_feats is None:
+        return offsets
+    return np.concatenate([_group_gather(np.asarray(s_feats, dtype=np.float32), neighbor_indices), offsets], axis=1)
+
+
+def edge_group(q_feats, s_feats, neighbor_indices):
+    """layers/edge_conv.py:59-61: cat([q.expand, group_gather(feats) - q.expand], dim=1)."""
+    g = _group_gather(np.asarray(s_feats, dtype=np.float32), neighbor_indices)
+    q = np.broadcast_to(np.asarray(q_feats, dtype=np.float32)[:, :, :, None], g.shape)
+    return np.concatenate([q, g - q], axis=1)

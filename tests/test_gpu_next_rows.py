@@ -245,3 +245,62 @@ def test_pack_ops_wrappers_and_autograd(ext, oracle_mod):
     assert ops.index_select(x, idx, dim=1).shape == (4, 2, 2, 5)
     with pytest.raises(RuntimeError, match="CUDA"):
         ops.local_maxpool_pack_mode(torch.zeros(4, 4), torch.zeros(2, 2, dtype=torch.long))
+
+
+# ------------------------------------------------------------------------------------------------------
+# rank 4: fused grouping (set abstraction / EdgeConv MLP inputs)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,c,n,m,k", [(2, 0, 64, 16, 4), (3, 5, 100, 33, 7), (8, 64, 1024, 512, 32),
+                                       (2, 16, 4096, 1024, 16), (1, 6, 8192, 700, 20), (2, 3, 10000, 300, 9),
+                                       (4, 32, 1000, 1000, 20)])
+def test_fused_group_bit_exact(ext, oracle_mod, b, c, n, m, k):
+    rng = np.random.default_rng(b + c + n + m + k)
+    s_points = rng.random((b, 3, n), dtype=np.float32)
+    q_points = np.ascontiguousarray(s_points[:, :, :m]) if m <= n else rng.random((b, 3, m), dtype=np.float32)
+    idx = rng.integers(0, n, size=(b, m, k)).astype(np.int64)
+    s_feats = rng.standard_normal((b, c, n)).astype(np.float32) if c else None
+    out = torch.empty((b, c + 3, m, k), device=DEV)
+    ext.sa_group(T(q_points), T(s_points), T(s_feats) if c else None, T(idx), out)
+    assert np.array_equal(N_(out), oracle_mod.sa_group(q_points, s_points, s_feats, idx))
+    if c:
+        q_feats = rng.standard_normal((b, c, m)).astype(np.float32)
+        out = torch.empty((b, 2 * c, m, k), device=DEV)
+        ext.edge_group(T(q_feats), T(s_feats), T(idx), out)
+        assert np.array_equal(N_(out), oracle_mod.edge_group(q_feats, s_feats, idx))
+
+
+def test_fused_group_equals_reference_formulation_and_autograd(ext):
+    """The reference formulation itself (group_gather + subtract + cat, pointnet2.py:44-47 / edge_conv.py:59-61) built
+    from the hot-path ops, forward and backward."""
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(21)
+    b, c, n, m, k = 2, 8, 512, 128, 16
+    s_points = T(rng.random((b, 3, n), dtype=np.float32)).requires_grad_(True)
+    q_points = T(rng.random((b, 3, m), dtype=np.float32)).requires_grad_(True)
+    s_feats = T(rng.standard_normal((b, c, n)).astype(np.float32)).requires_grad_(True)
+    q_feats = T(rng.standard_normal((b, c, m)).astype(np.float32)).requires_grad_(True)
+    idx = T(rng.integers(0, n, size=(b, m, k)).astype(np.int64))
+    up = T(rng.standard_normal((b, c + 3, m, k)).astype(np.float32))
+    ref = torch.cat([ops.group_gather(s_feats, idx), ops.group_gather(s_points, idx) - q_points.unsqueeze(3)], dim=1)
+    ref.backward(up)
+    want = [t.grad.clone() for t in (q_points, s_points, s_feats)]
+    for t in (q_points, s_points, s_feats):
+        t.grad = None
+    got = ops.sa_group(q_points, s_points, s_feats, idx)
+    assert torch.equal(got, ref)
+    got.backward(up)
+    assert torch.equal(s_points.grad, want[1]) and torch.equal(s_feats.grad, want[2])
+    assert torch.allclose(q_points.grad, want[0], rtol=1e-5, atol=1e-5)
+    s_feats.grad = None
+    up2 = T(rng.standard_normal((b, 2 * c, m, k)).astype(np.float32))
+    g = ops.group_gather(s_feats, idx)
+    qe = q_feats.unsqueeze(3).expand_as(g)
+    ref = torch.cat([qe, g - qe], dim=1)
+    ref.backward(up2)
+    want = [q_feats.grad.clone(), s_feats.grad.clone()]
+    q_feats.grad = s_feats.grad = None
+    got = ops.edge_group(q_feats, s_feats, idx)
+    assert torch.equal(got, ref)
+    got.backward(up2)
+    assert torch.equal(s_feats.grad, want[1]) and torch.allclose(q_feats.grad, want[0], rtol=1e-5, atol=1e-5)

@@ -117,6 +117,90 @@ def main():
             lambda pts=pts, lengths=lengths, o=o, ol=ol, num=num, vs=vs: ext.grid_subsample_pack(pts, lengths, o, ol,
                                                                                                  num, vs),
             nc * n, "Mpts/s")
+    # ---- mutual top-k selection (native vs the reference's torch formulation on the same GPU) -------
+    from vision3d_amd import ops  # noqa: E402
+
+    def torch_mutual_topk(score, k):  # the reference's formulation (ops/mutual_topk_select.py:31-58), for comparison only
+        n, m = score.shape
+        rt = score.topk(k=k, largest=False, dim=1)[1]
+        rm = torch.zeros_like(score, dtype=torch.bool)
+        rm[torch.arange(n, device=DEV).view(n, 1).expand(-1, k), rt] = True
+        ct = score.topk(k=k, largest=False, dim=0)[1]
+        cm = torch.zeros_like(score, dtype=torch.bool)
+        cm[ct, torch.arange(m, device=DEV).view(1, m).expand(k, -1)] = True
+        corr = torch.logical_and(rm, cm)
+        r, c = torch.nonzero(corr, as_tuple=True)
+        return r, c, score[r, c]
+
+    for (n, m, k) in ((512, 512, 3), (4096, 4096, 3), (16384, 16384, 1)):
+        score = torch.rand((n, m), generator=g).to(DEV)
+        add(f"mutual_topk_select N{n} M{m} k{k}", lambda score=score, k=k: ops.mutual_topk_select(score, k, largest=False),
+            n * m, "Mcells/s")
+        add(f"mutual_topk_select_torchref N{n} M{m} k{k}", lambda score=score, k=k: torch_mutual_topk(score, k),
+            n * m, "Mcells/s")
+    for (n, m, c) in ((20000, 20000, 256), (100000, 100000, 256)):
+        x = torch.nn.functional.normalize(torch.randn((n, c), generator=g), dim=1).to(DEV)
+        y = torch.nn.functional.normalize(torch.randn((m, c), generator=g), dim=1).to(DEV)
+        add(f"mutual_nn_from_feats N{n} M{m} C{c}",
+            lambda x=x, y=y: ops.extract_correspondences_from_feats(x, y, mutual=True), 4.0 * n * m * c / 1e6, "TFLOP/s")
+    # ---- pack-mode row gathers (KPConv stage shapes: 16 x 30,000 points, 38 neighbours) ------------
+    for (n, k, c) in ((480000, 38, 64), (120000, 36, 256)):
+        feats = torch.randn((n, c), generator=g).to(DEV)
+        table = torch.randint(0, n + 1, (n, k), generator=g).to(DEV)
+        # neighbours of a point are near it in memory after grid subsampling: indices within +-2000 rows
+        near = (torch.arange(n).view(n, 1) + torch.randint(-2000, 2000, (n, k), generator=g)).clamp_(0, n).to(DEV)
+        out3 = torch.empty((n, k, c), device=DEV)
+        out2 = torch.empty((n, c), device=DEV)
+        argk = torch.empty((n, c), dtype=torch.uint8, device=DEV)
+        w = torch.rand((n, k), generator=g).to(DEV)
+        gb_gather = (n * k * (8 + 4 * c) + 4 * n * c) / 1e3  # idx + written rows + source once, in KB -> GB/s via 1e6
+        gb_pool = (n * k * 8 + 4 * n * c * 2) / 1e3
+        for tname, tb in (("random", table), ("local", near)):
+            add(f"index_select_rows {tname} N{n} K{k} C{c}", lambda feats=feats, tb=tb, out3=out3: ext.index_select_rows(feats, tb, out3),
+                gb_gather, "GB/s")
+            add(f"local_maxpool_pack {tname} N{n} K{k} C{c}",
+                lambda feats=feats, tb=tb, out2=out2, argk=argk: ext.local_maxpool_pack(feats, tb, out2, argk), gb_pool, "GB/s(alg)")
+            add(f"rows_weighted_sum {tname} N{n} K{k} C{c}",
+                lambda feats=feats, tb=tb, out2=out2, w=w: ext.rows_weighted_sum(feats, tb, w, out2), gb_pool, "GB/s(alg)")
+        padded = torch.cat([feats, torch.zeros_like(feats[:1])], 0)
+        add(f"local_maxpool_torchref local N{n} K{k} C{c}",
+            lambda padded=padded, near=near: padded.index_select(0, near.view(-1)).view(near.shape[0], near.shape[1], -1).max(1)[0],
+            gb_pool, "GB/s(alg)")
+        add(f"rows_csr_build N{n} K{k}", lambda near=near, n=n: ext.rows_csr_build(near, n), n * k, "Mentries/s")
+        csr = ext.rows_csr_build(near, n) if (not want or any("rows_scatter" in w_ for w_ in want) or any("N%d" % n in w_ for w_ in want)) else None
+        if csr is not None:
+            gs = torch.empty((n, c), device=DEV)
+            add(f"rows_scatter mode0 local N{n} K{k} C{c}",
+                lambda out3=out3, csr=csr, gs=gs, n=n, k=k, c=c: ext.rows_scatter(out3.view(n * k, c), csr, gs, (n * k, 1), mode=0),
+                gb_gather, "GB/s")
+            add(f"rows_scatter mode2 local N{n} K{k} C{c}",
+                lambda out2=out2, csr=csr, gs=gs, argk=argk, n=n, k=k: ext.rows_scatter(out2, csr, gs, (n, k), mode=2, argk=argk),
+                gb_pool, "GB/s(alg)")
+    # ---- fused grouping vs the reference's three-pass formulation built from our own ops ------------
+    for (B, C, N, M, K) in ((32, 64, 4096, 1024, 32), (32, 64, 4096, 1024, 128), (32, 64, 1024, 1024, 20)):
+        sp = torch.rand((B, 3, N), generator=g).to(DEV)
+        qp = sp[:, :, :M].contiguous()
+        sf = torch.randn((B, C, N), generator=g).to(DEV)
+        qf = torch.randn((B, C, M), generator=g).to(DEV)
+        gi = torch.randint(0, N, (B, M, K), generator=g).to(DEV)
+        o_sa = torch.empty((B, C + 3, M, K), device=DEV)
+        o_ed = torch.empty((B, 2 * C, M, K), device=DEV)
+        by_sa = (B * M * K * 8 + 4 * B * (C + 3) * (N + M * K) + 4 * B * 3 * M) / 1e3
+        by_ed = (B * M * K * 8 + 4 * B * C * (N + M) + 4 * B * 2 * C * M * K) / 1e3
+        add(f"sa_group B{B} C{C} N{N} M{M} K{K}", lambda qp=qp, sp=sp, sf=sf, gi=gi, o=o_sa: ext.sa_group(qp, sp, sf, gi, o),
+            by_sa, "GB/s")
+
+        def three_pass_sa(qp=qp, sp=sp, sf=sf, gi=gi):
+            return torch.cat([ops.group_gather(sf, gi), ops.group_gather(sp, gi) - qp.unsqueeze(3)], dim=1)
+        add(f"sa_group_threepass B{B} C{C} N{N} M{M} K{K}", three_pass_sa, by_sa, "GB/s")
+        add(f"edge_group B{B} C{C} N{N} M{M} K{K}", lambda qf=qf, sf=sf, gi=gi, o=o_ed: ext.edge_group(qf, sf, gi, o),
+            by_ed, "GB/s")
+
+        def three_pass_edge(qf=qf, sf=sf, gi=gi):
+            nb = ops.group_gather(sf, gi)
+            qe = qf.unsqueeze(3).expand_as(nb)
+            return torch.cat([qe, nb - qe], dim=1)
+        add(f"edge_group_threepass B{B} C{C} N{N} M{M} K{K}", three_pass_edge, by_ed, "GB/s")
     for name, fn, work, unit in cases:
         med, mn = timeit(fn)
         rate = (work / (med * 1e-3) / 1e6) if work else 0.0  # work/1e6 per second

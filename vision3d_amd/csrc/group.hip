@@ -1,0 +1,252 @@
+// group.hip -- fused neighbourhood grouping of the batch-mode layers.
+// The reference builds the input of a set-abstraction MLP in three passes over the (B,C,M,K) tensor
+// (layers/pointnet2.py:44-47):  group_gather(points) -> subtract the centroid -> group_gather(feats) -> torch.cat,
+// and the input of an EdgeConv MLP the same way (layers/edge_conv.py:59-61): group_gather(feats) -> expand(q) ->
+// cat([q, neighbours - q]).  Each intermediate is a full HBM round trip of the largest tensor of the layer.
+//
+// Here ONE kernel writes the MLP input directly.  Output channels come in three kinds, in this order:
+//   [ plain : out = src0[b,c,idx] ] [ broadcast : out = ctr[b,c,m] ] [ offset : out = src1[b,c,idx] - ctr[b,c,m] ]
+//   set abstraction : plain = C feature channels, broadcast = 0, offset = 3 coordinates        (C+3 channels)
+//   EdgeConv        : plain = 0, broadcast = C, offset = C                                      (2C channels)
+// Structure = the group-gather forward (gather.hip): a workgroup owns 8192 target positions of one cloud and walks a
+// tile of output channels with its 32 indices in registers; the source row of the channel is staged in LDS (double
+// buffered, next row in flight), the centroid values of the tile's queries sit in LDS beside it; 16-byte streaming
+// stores.  The subtraction is the single fp32 operation the reference performs, so results are bit-identical to it.
+#include <algorithm>
+
+#include "common.h"
+
+namespace v3d {
+
+constexpr int kGrpThreads = 256;
+constexpr int kGrpVec = 4;
+constexpr int kGrpR = 8;                                   // vectors per thread
+constexpr int kGrpTile = kGrpThreads * kGrpVec * kGrpR;    // 8192 target positions per workgroup
+constexpr int kGrpRowVecs = 8;                             // 16-byte pieces of a source row per thread: N <= 8192
+constexpr int kGrpCtrVals = 4;                             // centre values per thread: <= 1024 queries per tile
+
+struct GroupArgs {
+  const float* src0;  // (B, C0, N) plain channels (may be null when C0 == 0)
+  const float* src1;  // (B, C1, N) offset channels
+  const float* ctr;   // (B, Cb + C1 or C1, M) centre values: broadcast channels first when share_ctr == 0
+  int C0, Cb, C1;
+  int share_ctr;      // 1: broadcast channel c and offset channel c read the same centre row (EdgeConv)
+  int N, M, K;
+};
+
+// kind / source row / centre row of output channel oc
+__device__ __forceinline__ void grp_channel(const GroupArgs& a, int b, int oc, const float*& row, const float*& crow) {
+  row = nullptr;
+  crow = nullptr;
+  if (oc < a.C0) {
+    row = a.src0 + ((int64_t)b * a.C0 + oc) * a.N;
+  } else if (oc < a.C0 + a.Cb) {
+    const int c = oc - a.C0;
+    const int cc = a.share_ctr ? a.C1 : a.Cb + a.C1;
+    crow = a.ctr + ((int64_t)b * cc + c) * a.M;
+  } else {
+    const int c = oc - a.C0 - a.Cb;
+    const int cc = a.share_ctr ? a.C1 : a.Cb + a.C1;
+    row = a.src1 + ((int64_t)b * a.C1 + c) * a.N;
+    crow = a.ctr + ((int64_t)b * cc + (a.share_ctr ? c : a.Cb + c)) * a.M;
+  }
+}
+
+// KV: K % 4 == 0, so the four positions of a vector share one query.
+template <bool KV>
+__global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs a, const int64_t* __restrict__ idx,
+                                                                      float* __restrict__ out, int CT, int row_elems,
+                                                                      int ctr_elems, GridMap gm) {
+  extern __shared__ __align__(16) float grp_smem[];
+  float* rows = grp_smem;                         // 2 x row_elems: source row (+ zero slot at N)
+  float* ctrs = grp_smem + 2 * row_elems;         // 2 x ctr_elems: centre values of this tile's queries
+  const int tid = threadIdx.x;
+  int bx, by, b;
+  decode_block(gm, bx, by, b);
+  const int Cout = a.C0 + a.Cb + a.C1;
+  const int c0 = by * CT, c1 = min(c0 + CT, Cout);
+  const int64_t L = (int64_t)a.M * a.K;
+  const int64_t tile0 = (int64_t)bx * kGrpTile;
+  const int m_first = (int)(tile0 / a.K);
+  const int m_count = (int)(min(L, tile0 + kGrpTile) - 1) / a.K - m_first + 1;
+
+  int my[kGrpR][kGrpVec];
+  int mq[kGrpR][KV ? 1 : kGrpVec];
+  const int64_t* bidx = idx + (int64_t)b * L;
+#pragma unroll
+  for (int r = 0; r < kGrpR; ++r) {
+    const int64_t p0 = tile0 + ((int64_t)r * kGrpThreads + tid) * kGrpVec;
+#pragma unroll
+    for (int e = 0; e < kGrpVec; ++e) {
+      int v = a.N;
+      if (p0 + e < L) {
+        const int64_t raw = bidx[p0 + e];
+        v = (raw >= 0 && raw < a.N) ? (int)raw : a.N;
+      }
+      my[r][e] = v;
+      if (!KV || e == 0) mq[r][KV ? 0 : e] = (p0 + e < L) ? (int)((p0 + e) / a.K) - m_first : 0;
+    }
+  }
+  if (tid == 0) {
+    rows[a.N] = 0.f;
+    rows[row_elems + a.N] = 0.f;
+  }
+  // register staging: the next channel's source row (16-byte pieces) and centre values are requested before this
+  // channel's gathers and stores and written to the other LDS buffer after them
+  const int nvec = a.N >> 2;
+  uint4 stg[kGrpRowVecs];
+  float cst[kGrpCtrVals];
+  bool st_row = false, st_ctr = false;
+  auto issue = [&](int oc) {
+    const float *row, *crow;
+    grp_channel(a, b, oc, row, crow);
+    st_row = row != nullptr;
+    st_ctr = crow != nullptr;
+    const uint4* row4 = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+    for (int i = 0; i < kGrpRowVecs; ++i) {
+      const int v = i * kGrpThreads + tid;
+      stg[i] = (st_row && v < nvec) ? row4[v] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kGrpCtrVals; ++i) {
+      const int v = i * kGrpThreads + tid;
+      cst[i] = (st_ctr && v < m_count) ? crow[m_first + v] : 0.f;
+    }
+  };
+  auto commit = [&](int which) {
+    uint4* dr = reinterpret_cast<uint4*>(rows + which * row_elems);
+    float* dc = ctrs + which * ctr_elems;
+    if (st_row) {
+#pragma unroll
+      for (int i = 0; i < kGrpRowVecs; ++i) {
+        const int v = i * kGrpThreads + tid;
+        if (v < nvec) dr[v] = stg[i];
+      }
+    }
+    if (st_ctr) {
+#pragma unroll
+      for (int i = 0; i < kGrpCtrVals; ++i) {
+        const int v = i * kGrpThreads + tid;
+        if (v < m_count) dc[v] = cst[i];
+      }
+    }
+  };
+  issue(c0);
+  commit(0);
+  for (int oc = c0; oc < c1; ++oc) {
+    __syncthreads();
+    const int which = (oc - c0) & 1;
+    const float* cur = rows + which * row_elems;
+    const float* cc = ctrs + which * ctr_elems;
+    const bool have_next = oc + 1 < c1;
+    if (have_next) issue(oc + 1);
+    const bool has_row = oc < a.C0 || oc >= a.C0 + a.Cb;
+    const bool has_ctr = oc >= a.C0;
+    float* orow = out + ((int64_t)b * Cout + oc) * L;
+#pragma unroll
+    for (int r = 0; r < kGrpR; ++r) {
+      const int64_t p0 = tile0 + ((int64_t)r * kGrpThreads + tid) * kGrpVec;
+      if (p0 < L) {
+        float v[kGrpVec];
+#pragma unroll
+        for (int e = 0; e < kGrpVec; ++e) {
+          const float g = has_row ? cur[my[r][e]] : 0.f;
+          const float q = has_ctr ? cc[mq[r][KV ? 0 : e]] : 0.f;
+          v[e] = has_row ? (has_ctr ? g - q : g) : q;
+        }
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 pk = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(pk, reinterpret_cast<f32x4*>(orow + p0));
+      }
+    }
+    if (have_next) commit(which ^ 1);  // that buffer was last read before this iteration's barrier
+  }
+}
+
+// Generic path (any N, any L): one thread per target position, everything from global memory / L2.
+__global__ __launch_bounds__(kGrpThreads) void group_fused_direct_kernel(GroupArgs a, const int64_t* __restrict__ idx,
+                                                                         float* __restrict__ out) {
+  const int b = blockIdx.z, oc = blockIdx.y;
+  const int64_t L = (int64_t)a.M * a.K;
+  const int64_t p = (int64_t)blockIdx.x * kGrpThreads + threadIdx.x;
+  if (p >= L) return;
+  const int Cout = a.C0 + a.Cb + a.C1;
+  const float *row, *crow;
+  grp_channel(a, b, oc, row, crow);
+  const int64_t raw = idx[(int64_t)b * L + p];
+  const bool ok = raw >= 0 && raw < a.N;
+  const float g = (row && ok) ? row[raw] : 0.f;
+  const float q = crow ? crow[p / a.K] : 0.f;
+  out[((int64_t)b * Cout + oc) * L + p] = row ? (crow ? g - q : g) : q;
+}
+
+static int launch_group_fused(const char* what, const GroupArgs& a, const int64_t* idx, float* out, int B,
+                              hipStream_t stream) {
+  const int Cout = a.C0 + a.Cb + a.C1;
+  const int64_t L = (int64_t)a.M * a.K;
+  if (B == 0 || Cout == 0 || L == 0) return 0;
+  if (B > kMaxGridYZ || Cout > kMaxGridYZ || L > (int64_t)INT32_MAX) {
+    set_last_error("%s: B, channels <= 65535 and M*K < 2^31 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  const int row_elems = (int)(align_up((size_t)(a.N + 1) * 4, 16) / 4);
+  const int ctr_elems = (int)(align_up((size_t)(kGrpTile / std::max(a.K, 1) + 2) * 4, 16) / 4);
+  const size_t lds = sizeof(float) * 2 * ((size_t)row_elems + ctr_elems);
+  const uintptr_t srcs = (uintptr_t)a.src0 | (uintptr_t)a.src1;
+  const bool lds_ok = a.N % 4 == 0 && a.N <= kGrpRowVecs * kGrpThreads * 4 && (srcs & 15) == 0 &&
+                      kGrpTile / a.K + 2 <= kGrpCtrVals * kGrpThreads && lds <= 65536 && L % kGrpVec == 0 &&
+                      ((uintptr_t)out & 15) == 0 && L >= kGrpTile / 4;
+  if (!lds_ok) {
+    hipLaunchKernelGGL(group_fused_direct_kernel, dim3((unsigned)ceil_div(L, kGrpThreads), Cout, B), dim3(kGrpThreads), 0,
+                       stream, a, idx, out);
+    return launch_status(what);
+  }
+  const int64_t xblocks = ceil_div(L, kGrpTile);
+  int CT = 16;
+  while (CT > 2 && xblocks * ceil_div(Cout, CT) * B * (kGrpThreads / 64) < 2048) CT >>= 1;
+  if (CT > Cout) CT = Cout;
+  const int64_t yblocks = ceil_div(Cout, CT);
+  const GridMap gm = make_grid_map(xblocks, yblocks, B);
+  const dim3 grid((unsigned)(xblocks * yblocks * B)), block(kGrpThreads);
+  if (a.K % kGrpVec == 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(group_fused_lds_kernel<true>), grid, block, lds, stream, a, idx, out, CT, row_elems,
+                       ctr_elems, gm);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(group_fused_lds_kernel<false>), grid, block, lds, stream, a, idx, out, CT,
+                       row_elems, ctr_elems, gm);
+  return launch_status(what);
+}
+
+}  // namespace v3d
+
+extern "C" {
+
+int v3d_sa_group_f32(const float* q_points, const float* s_points, const float* s_feats, const int64_t* indices,
+                     float* grouped, int B, int C, int N, int M, int K, int device, void* stream_) {
+  using namespace v3d;
+  const char* what = "sa_group";
+  V3D_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && K >= 0, what, "negative dimension");
+  if (B == 0 || M == 0 || K == 0) return 0;
+  V3D_REQUIRE(q_points && indices && grouped && (N == 0 || s_points) && (C == 0 || N == 0 || s_feats), what,
+              "null pointer");
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  GroupArgs a{s_feats, s_points, q_points, C, 0, 3, 0, N, M, K};
+  return launch_group_fused(what, a, indices, grouped, B, static_cast<hipStream_t>(stream_));
+}
+
+int v3d_edge_group_f32(const float* q_feats, const float* s_feats, const int64_t* indices, float* grouped, int B, int C,
+                       int N, int M, int K, int device, void* stream_) {
+  using namespace v3d;
+  const char* what = "edge_group";
+  V3D_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && K >= 0, what, "negative dimension");
+  if (B == 0 || M == 0 || K == 0 || C == 0) return 0;
+  V3D_REQUIRE(q_feats && indices && grouped && (N == 0 || s_feats), what, "null pointer");
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  GroupArgs a{nullptr, s_feats, q_feats, 0, C, C, 1, N, M, K};
+  return launch_group_fused(what, a, indices, grouped, B, static_cast<hipStream_t>(stream_));
+}
+
+}  // extern "C"

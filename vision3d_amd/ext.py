@@ -40,6 +40,8 @@ __all__ = [
     "global_avgpool_pack",
     "rows_csr_build",
     "rows_scatter",
+    "sa_group",
+    "edge_group",
 ]
 
 _FLOATING = {torch.float32: "f32", torch.float64: "f64"}
@@ -563,3 +565,42 @@ def rows_scatter(target_grads, csr, source_grads, table_shape, mode=0, weights=N
     _lib.check(_lib.lib().v3d_rows_scatter_f32(target_grads.data_ptr(), csr.data_ptr(), _ptr(weights), _ptr(argk),
                                                int(mode), source_grads.data_ptr(), M * K, N, K, k_used, C, dev, stream),
                "rows_scatter")
+
+
+# --------------------------------------------------------------------------------------------------------
+# Fused grouping of the batch-mode layers: group_gather + subtract + cat in the reference.
+# --------------------------------------------------------------------------------------------------------
+def sa_group(q_points, s_points, s_feats, indices, grouped):
+    """q_points (B,3,M), s_points (B,3,N), s_feats (B,C,N) or None, indices (B,M,K) -> grouped (B,C+3,M,K)."""
+    tensors = [(q_points, "q_points"), (s_points, "s_points"), (grouped, "grouped")]
+    if s_feats is not None:
+        tensors.append((s_feats, "s_feats"))
+    for t, n in tensors:
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(indices, "indices")
+    _check_long(indices, "indices")
+    B, _, N = s_points.shape
+    M, K = indices.shape[1], indices.shape[2]
+    C = s_feats.shape[1] if s_feats is not None else 0
+    if q_points.shape[1] != 3 or s_points.shape[1] != 3 or tuple(grouped.shape) != (B, C + 3, M, K):
+        raise RuntimeError("sa_group: expected q_points (B,3,M), s_points (B,3,N), grouped (B,C+3,M,K)")
+    dev, stream = _where(s_points)
+    _lib.check(_lib.lib().v3d_sa_group_f32(q_points.data_ptr(), s_points.data_ptr(), _ptr(s_feats), indices.data_ptr(),
+                                           grouped.data_ptr(), B, C, N, M, K, dev, stream), "sa_group")
+
+
+def edge_group(q_feats, s_feats, indices, grouped):
+    """q_feats (B,C,M), s_feats (B,C,N), indices (B,M,K) -> grouped (B,2C,M,K) = cat([q, neighbours - q])."""
+    for t, n in ((q_feats, "q_feats"), (s_feats, "s_feats"), (grouped, "grouped")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(indices, "indices")
+    _check_long(indices, "indices")
+    B, C, N = s_feats.shape
+    M, K = indices.shape[1], indices.shape[2]
+    if tuple(q_feats.shape) != (B, C, M) or tuple(grouped.shape) != (B, 2 * C, M, K):
+        raise RuntimeError("edge_group: expected q_feats (B,C,M), grouped (B,2C,M,K)")
+    dev, stream = _where(s_feats)
+    _lib.check(_lib.lib().v3d_edge_group_f32(q_feats.data_ptr(), s_feats.data_ptr(), indices.data_ptr(),
+                                             grouped.data_ptr(), B, C, N, M, K, dev, stream), "edge_group")

@@ -8,6 +8,7 @@ package as ``vision3d.ops`` / ``vision3d.ext`` so unchanged model code imports i
 from .ball_query import ball_query
 from .conversion import batch_to_pack, batch_to_pack_with_lengths, pack_to_batch
 from .furthest_point_sample import furthest_point_sample
+from .fused_group import edge_group, sa_group
 from .gather import gather
 from .group_gather import group_gather
 from .knn import knn, knn_pack_mode
@@ -28,5 +29,5 @@ __all__ = [
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats",
     "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
-    "knn_interpolate_pack_mode",
+    "knn_interpolate_pack_mode", "sa_group", "edge_group",
 ]
