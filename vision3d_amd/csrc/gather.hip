@@ -284,6 +284,9 @@ static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, i
   return launch_status("gather_forward");
 }
 
+int group_fused_plain_u32(const void* src, const int64_t* idx, void* out, int B, int C, int N, int64_t L,
+                          hipStream_t stream);  // group.hip: 1 = shape not eligible
+
 static int gather_fwd_dispatch(const char* what, const void* src, const int64_t* idx, void* out, int B, int C,
                                int N, int64_t L, int elem, int device, void* stream_) {
   V3D_REQUIRE(B >= 0 && C >= 0 && N >= 0 && L >= 0, what, "negative dimension");
@@ -297,6 +300,11 @@ static int gather_fwd_dispatch(const char* what, const void* src, const int64_t*
   DeviceGuard guard(device);
   if (guard.rc) return guard.rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  static const int fused = getenv("V3D_GATHER_FUSED") ? atoi(getenv("V3D_GATHER_FUSED")) : 1;  // 0: tuning aid
+  if (fused && elem == 4) {
+    const int rc = group_fused_plain_u32(src, idx, out, B, C, N, L, stream);
+    if (rc != 1) return rc;
+  }
   switch (elem) {
     case 1: return launch_gather_fwd<uint8_t, 4>(src, idx, out, B, C, N, L, stream);
     case 2: return launch_gather_fwd<uint16_t, 4>(src, idx, out, B, C, N, L, stream);

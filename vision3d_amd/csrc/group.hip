@@ -53,7 +53,8 @@ __device__ __forceinline__ void grp_channel(const GroupArgs& a, int b, int oc, c
 }
 
 // KV: K % 4 == 0, so the four positions of a vector share one query.
-template <bool KV>
+// CTR: the launch has broadcast / offset channels (false = plain gather: no query bookkeeping at all).
+template <bool KV, bool CTR, int NSTAGE>
 __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs a, const int64_t* __restrict__ idx,
                                                                       float* __restrict__ out, int CT, int row_elems,
                                                                       int ctr_elems, GridMap gm) {
@@ -73,18 +74,23 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs 
   int my[kGrpR][kGrpVec];
   int mq[kGrpR][KV ? 1 : kGrpVec];
   const int64_t* bidx = idx + (int64_t)b * L;
+  const bool idx_vec = (reinterpret_cast<uintptr_t>(bidx) & 15) == 0;
 #pragma unroll
   for (int r = 0; r < kGrpR; ++r) {
     const int64_t p0 = tile0 + ((int64_t)r * kGrpThreads + tid) * kGrpVec;
+    int64_t raw[kGrpVec];
+    if (idx_vec && p0 + kGrpVec <= L) {  // two int64 per 16-byte load
+      const longlong2* src2 = reinterpret_cast<const longlong2*>(bidx + p0);
+      const longlong2 t0 = src2[0], t1 = src2[1];
+      raw[0] = t0.x; raw[1] = t0.y; raw[2] = t1.x; raw[3] = t1.y;
+    } else {
+#pragma unroll
+      for (int e = 0; e < kGrpVec; ++e) raw[e] = (p0 + e < L) ? bidx[p0 + e] : -1;
+    }
 #pragma unroll
     for (int e = 0; e < kGrpVec; ++e) {
-      int v = a.N;
-      if (p0 + e < L) {
-        const int64_t raw = bidx[p0 + e];
-        v = (raw >= 0 && raw < a.N) ? (int)raw : a.N;
-      }
-      my[r][e] = v;
-      if (!KV || e == 0) mq[r][KV ? 0 : e] = (p0 + e < L) ? (int)((p0 + e) / a.K) - m_first : 0;
+      my[r][e] = (raw[e] >= 0 && raw[e] < a.N) ? (int)raw[e] : a.N;
+      if (CTR && (!KV || e == 0)) mq[r][KV ? 0 : e] = (p0 + e < L) ? (int)((p0 + e) / a.K) - m_first : 0;
     }
   }
   if (tid == 0) {
@@ -94,24 +100,26 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs 
   // register staging: the next channel's source row (16-byte pieces) and centre values are requested before this
   // channel's gathers and stores and written to the other LDS buffer after them
   const int nvec = a.N >> 2;
-  uint4 stg[kGrpRowVecs];
+  uint4 stg[NSTAGE];
   float cst[kGrpCtrVals];
   bool st_row = false, st_ctr = false;
   auto issue = [&](int oc) {
     const float *row, *crow;
     grp_channel(a, b, oc, row, crow);
     st_row = row != nullptr;
-    st_ctr = crow != nullptr;
+    st_ctr = CTR && crow != nullptr;
     const uint4* row4 = reinterpret_cast<const uint4*>(row);
 #pragma unroll
-    for (int i = 0; i < kGrpRowVecs; ++i) {
+    for (int i = 0; i < NSTAGE; ++i) {
       const int v = i * kGrpThreads + tid;
       stg[i] = (st_row && v < nvec) ? row4[v] : make_uint4(0, 0, 0, 0);
     }
+    if (CTR) {
 #pragma unroll
-    for (int i = 0; i < kGrpCtrVals; ++i) {
-      const int v = i * kGrpThreads + tid;
-      cst[i] = (st_ctr && v < m_count) ? crow[m_first + v] : 0.f;
+      for (int i = 0; i < kGrpCtrVals; ++i) {
+        const int v = i * kGrpThreads + tid;
+        cst[i] = (st_ctr && v < m_count) ? crow[m_first + v] : 0.f;
+      }
     }
   };
   auto commit = [&](int which) {
@@ -119,12 +127,12 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs 
     float* dc = ctrs + which * ctr_elems;
     if (st_row) {
 #pragma unroll
-      for (int i = 0; i < kGrpRowVecs; ++i) {
+      for (int i = 0; i < NSTAGE; ++i) {
         const int v = i * kGrpThreads + tid;
         if (v < nvec) dr[v] = stg[i];
       }
     }
-    if (st_ctr) {
+    if (CTR && st_ctr) {
 #pragma unroll
       for (int i = 0; i < kGrpCtrVals; ++i) {
         const int v = i * kGrpThreads + tid;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs 
     const bool have_next = oc + 1 < c1;
     if (have_next) issue(oc + 1);
     const bool has_row = oc < a.C0 || oc >= a.C0 + a.Cb;
-    const bool has_ctr = oc >= a.C0;
+    const bool has_ctr = CTR && oc >= a.C0;
     float* orow = out + ((int64_t)b * Cout + oc) * L;
 #pragma unroll
     for (int r = 0; r < kGrpR; ++r) {
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs 
 #pragma unroll
         for (int e = 0; e < kGrpVec; ++e) {
           const float g = has_row ? cur[my[r][e]] : 0.f;
-          const float q = has_ctr ? cc[mq[r][KV ? 0 : e]] : 0.f;
+          const float q = (CTR && has_ctr) ? cc[mq[r][KV ? 0 : e]] : 0.f;
           v[e] = has_row ? (has_ctr ? g - q : g) : q;
         }
         typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -181,6 +189,17 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_direct_kernel(GroupAr
   out[((int64_t)b * Cout + oc) * L + p] = row ? (crow ? g - q : g) : q;
 }
 
+static bool group_lds_ok(const GroupArgs& a, const float* out) {
+  const int64_t L = (int64_t)a.M * a.K;
+  const size_t row_elems = align_up((size_t)(a.N + 1) * 4, 16) / 4;
+  const size_t ctr_elems = align_up((size_t)(kGrpTile / std::max(a.K, 1) + 2) * 4, 16) / 4;
+  const size_t lds = sizeof(float) * 2 * (row_elems + ctr_elems);
+  const uintptr_t srcs = (uintptr_t)a.src0 | (uintptr_t)a.src1;
+  return a.N % 4 == 0 && a.N <= kGrpRowVecs * kGrpThreads * 4 && (srcs & 15) == 0 &&
+         kGrpTile / std::max(a.K, 1) + 2 <= kGrpCtrVals * kGrpThreads && lds <= 65536 && L % kGrpVec == 0 &&
+         ((uintptr_t)out & 15) == 0 && L >= kGrpTile / 4;
+}
+
 static int launch_group_fused(const char* what, const GroupArgs& a, const int64_t* idx, float* out, int B,
                               hipStream_t stream) {
   const int Cout = a.C0 + a.Cb + a.C1;
@@ -193,10 +212,7 @@ static int launch_group_fused(const char* what, const GroupArgs& a, const int64_
   const int row_elems = (int)(align_up((size_t)(a.N + 1) * 4, 16) / 4);
   const int ctr_elems = (int)(align_up((size_t)(kGrpTile / std::max(a.K, 1) + 2) * 4, 16) / 4);
   const size_t lds = sizeof(float) * 2 * ((size_t)row_elems + ctr_elems);
-  const uintptr_t srcs = (uintptr_t)a.src0 | (uintptr_t)a.src1;
-  const bool lds_ok = a.N % 4 == 0 && a.N <= kGrpRowVecs * kGrpThreads * 4 && (srcs & 15) == 0 &&
-                      kGrpTile / a.K + 2 <= kGrpCtrVals * kGrpThreads && lds <= 65536 && L % kGrpVec == 0 &&
-                      ((uintptr_t)out & 15) == 0 && L >= kGrpTile / 4;
+  const bool lds_ok = group_lds_ok(a, out);
   if (!lds_ok) {
     hipLaunchKernelGGL(group_fused_direct_kernel, dim3((unsigned)ceil_div(L, kGrpThreads), Cout, B), dim3(kGrpThreads), 0,
                        stream, a, idx, out);
@@ -209,13 +225,36 @@ static int launch_group_fused(const char* what, const GroupArgs& a, const int64_
   const int64_t yblocks = ceil_div(Cout, CT);
   const GridMap gm = make_grid_map(xblocks, yblocks, B);
   const dim3 grid((unsigned)(xblocks * yblocks * B)), block(kGrpThreads);
-  if (a.K % kGrpVec == 0)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(group_fused_lds_kernel<true>), grid, block, lds, stream, a, idx, out, CT, row_elems,
-                       ctr_elems, gm);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(group_fused_lds_kernel<false>), grid, block, lds, stream, a, idx, out, CT,
-                       row_elems, ctr_elems, gm);
+#define V3D_GRP_LAUNCH_NS(KV, CTR, NS)                                                                                \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(group_fused_lds_kernel<KV, CTR, NS>), grid, block, lds, stream, a, idx, out, CT, \
+                     row_elems, ctr_elems, gm)
+#define V3D_GRP_LAUNCH(KV, CTR)                            \
+  do {                                                     \
+    if (per_thread <= 1) V3D_GRP_LAUNCH_NS(KV, CTR, 1);    \
+    else if (per_thread <= 2) V3D_GRP_LAUNCH_NS(KV, CTR, 2); \
+    else if (per_thread <= 4) V3D_GRP_LAUNCH_NS(KV, CTR, 4); \
+    else V3D_GRP_LAUNCH_NS(KV, CTR, 8);                    \
+  } while (0)
+  const int per_thread = (int)ceil_div(a.N / 4, kGrpThreads);  // 16-byte pieces of a source row per thread
+  const bool ctr = a.Cb + a.C1 > 0;
+  if (!ctr) V3D_GRP_LAUNCH(true, false);
+  else if (a.K % kGrpVec == 0) V3D_GRP_LAUNCH(true, true);
+  else V3D_GRP_LAUNCH(false, true);
+#undef V3D_GRP_LAUNCH_NS
+#undef V3D_GRP_LAUNCH
   return launch_status(what);
+}
+
+// Plain 4-byte group gather through the same kernel: gather.hip routes there whenever the LDS path applies (it is
+// the faster of the two forward kernels on MI355X: 5.7 against 5.0 TB/s on the k = 128 grouping of BASELINE config 2).
+// Returns 1 when the shape is not eligible (nothing launched), else the launch status.
+int group_fused_plain_u32(const void* src, const int64_t* idx, void* out, int B, int C, int N, int64_t L,
+                          hipStream_t stream) {
+  // rows under 8 KiB: gather.hip's kernel is as fast or faster (measured: N=1024,K=20 36 vs 42 us)
+  if (L % 16 != 0 || L >= (int64_t)INT32_MAX || N < 2048) return 1;
+  GroupArgs a{static_cast<const float*>(src), nullptr, nullptr, C, 0, 0, 0, N, (int)(L / 16), 16};
+  if (!group_lds_ok(a, static_cast<float*>(out)) || B > kMaxGridYZ) return 1;
+  return launch_group_fused("group_gather_forward", a, idx, static_cast<float*>(out), B, stream);
 }
 
 }  // namespace v3d
