@@ -259,6 +259,21 @@ int v3d_sa_group_f32(const float* q_points, const float* s_points, const float* 
 int v3d_edge_group_f32(const float* q_feats, const float* s_feats, const int64_t* indices, float* grouped, int B, int C,
                        int N, int M, int K, int device, void* stream);
 
+/* ---- KPConv neighbourhood aggregation (fused gather + weighted sum) -------------------------------
+ * replaces the body of KPConv.forward up to the convolution weights (vision3d/layers/kpconv.py:100-115 and :137-139):
+ * q_points (M,3), s_points (N,3), s_feats (N,C), neighbor_indices (M,H) (entry N = none), kernel_points (K,3) ->
+ *   weighted_feats[m,k,:] = sum_h max(0, 1 - |s_points[idx[m,h]] - q_points[m] - kernel_points[k]| / sigma)
+ *                                 * s_feats[idx[m,h],:]                                            (M,K,C)
+ *   neighbor_num[m] = max(1, #{h : sum_c s_feats[idx[m,h],c] > 0})                                 (M,) int64, optional
+ * without the (M,H,3), (M,H,K,3), (M,H,K) and (M,H,C) intermediates.  H <= 64, K <= 16, C % 4 == 0, fp32-input MFMA
+ * (exact products; summation order over h is the MFMA's).  workspace: v3d_kpconv_gather_workspace_bytes(N) bytes when
+ * neighbor_num is requested (NULL = stream-ordered allocation). */
+size_t v3d_kpconv_gather_workspace_bytes(int64_t N);
+int v3d_kpconv_gather_f32(const float* q_points, const float* s_points, const float* s_feats,
+                          const int64_t* neighbor_indices, const float* kernel_points, float* weighted_feats,
+                          int64_t* neighbor_num, int64_t M, int64_t N, int H, int K, int C, float sigma, void* workspace,
+                          size_t workspace_bytes, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,26 @@ def edge_group(q_feats, s_feats, neighbor_indices):
     g = _group_gather(np.asarray(s_feats, dtype=np.float32), neighbor_indices)
     q = np.broadcast_to(np.asarray(q_feats, dtype=np.float32)[:, :, :, None], g.shape)
     return np.concatenate([q, g - q], axis=1)
+
+
+# ---- KPConv aggregation (layers/kpconv.py:97-141) -------------------------------------------------------------
+def kpconv_gather(q_points, s_points, s_feats, neighbor_indices, kernel_points, sigma, inf=1e6):
+    """weighted_feats (M,K,C) float32 (accumulated in float64: the order of the reference's batched GEMM is not part
+    of the contract) and neighbor_num (M,) int64, following kpconv.py:100-115 and :137-139 line by line."""
+    q = np.asarray(q_points, dtype=np.float32)
+    s = np.asarray(s_points, dtype=np.float32)
+    f = np.asarray(s_feats, dtype=np.float32)
+    kp = np.asarray(kernel_points, dtype=np.float32)
+    n = s.shape[0]
+    idx = _clamp(neighbor_indices, n)
+    padded_points = np.concatenate([s, np.zeros_like(s[:1]) + np.float32(inf)], axis=0)      # :100
+    neighbors = padded_points[idx] - q[:, None, :]                                             # :101-102
+    differences = neighbors[:, :, None, :] - kp[None, None, :, :]                              # :105-106
+    d2 = differences * differences
+    sq = (d2[..., 0] + d2[..., 1]) + d2[..., 2]                                                # :107
+    w = np.maximum(np.float32(1) - np.sqrt(sq) / np.float32(sigma), np.float32(0))             # :108
+    w = np.transpose(w, (0, 2, 1))                                                             # :109  (M,K,H)
+    neighbor_feats = _padded(f)[idx]                                                           # :112-113 (M,H,C)
+    weighted = np.matmul(w.astype(np.float64), neighbor_feats.astype(np.float64))              # :114
+    num = (neighbor_feats.sum(axis=-1, dtype=np.float64) > 0).sum(axis=-1)                     # :137-138
+    return weighted.astype(np.float32), np.maximum(num, 1).astype(np.int64), w

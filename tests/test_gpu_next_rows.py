@@ -304,3 +304,79 @@ def test_fused_group_equals_reference_formulation_and_autograd(ext):
     assert torch.equal(got, ref)
     got.backward(up2)
     assert torch.equal(s_feats.grad, want[1]) and torch.allclose(q_feats.grad, want[0], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# KPConv aggregation (fused gather + kernel-point influences + weighted sum)
+# ------------------------------------------------------------------------------------------------------
+def _kpconv_case(rng, n, m, h, k, c, radius=0.12):
+    s = rng.random((n, 3), dtype=np.float32)
+    q = np.ascontiguousarray(s[:m]) if m <= n else rng.random((m, 3), dtype=np.float32)
+    # neighbours = points within reach of the kernel, so that the influences are not all zero
+    d = np.linalg.norm(q[:, None, :] - s[None], axis=-1)
+    order = np.argsort(d, axis=1)[:, :h]
+    table = np.where(np.take_along_axis(d, order, 1) < radius * 1.5, order, n).astype(np.int64)
+    if table.shape[1] < h:
+        table = np.concatenate([table, np.full((m, h - table.shape[1]), n, dtype=np.int64)], axis=1)
+    feats = rng.standard_normal((n, c)).astype(np.float32)
+    feats[rng.random(n) < 0.2] = 0.0  # rows that do not count for the density normalisation
+    kpts = (rng.standard_normal((k, 3)) * radius * 0.5).astype(np.float32)
+    kpts[0] = 0
+    return q, s, feats, table, kpts
+
+
+@pytest.mark.parametrize("n,m,h,k,c", [(300, 200, 38, 15, 64), (500, 500, 17, 15, 128), (64, 40, 64, 16, 32),
+                                       (400, 333, 5, 7, 4), (1000, 800, 30, 15, 256), (200, 150, 1, 1, 68),
+                                       (50, 30, 0, 15, 8)])
+def test_kpconv_gather_vs_oracle(ext, oracle_mod, n, m, h, k, c):
+    rng = np.random.default_rng(n + m + h + k + c)
+    q, s, feats, table, kpts = _kpconv_case(rng, n, m, h, k, c)
+    sigma = 0.06
+    want, want_num, w = oracle_mod.kpconv_gather(q, s, feats, table, kpts, sigma)
+    out = torch.full((m, k, c), float("nan"), device=DEV)
+    num = torch.zeros((m,), dtype=torch.long, device=DEV)
+    ext.kpconv_gather(T(q), T(s), T(feats), T(table), T(kpts), out, num, sigma)
+    assert np.array_equal(N_(num), want_num)
+    # tolerance: 1e-5 of the summed magnitude sum_h w |f| (the order of the sum over neighbours is the MFMA's)
+    scale = np.matmul(w.astype(np.float64), np.abs(oracle_mod.index_select_rows(feats, table)).astype(np.float64))
+    assert np.all(np.abs(N_(out).astype(np.float64) - want) <= 1e-5 * scale + 1e-30)
+
+
+def test_kpconv_layer_forward_backward_matches_reference_formulation(ext, oracle_mod):
+    """ops.kpconv against the reference's formulation (kpconv.py:100-149) written with torch on the same device."""
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(77)
+    n, m, h, k, c, d = 600, 450, 24, 15, 32, 48
+    q, s, feats, table, kpts = _kpconv_case(rng, n, m, h, k, c)
+    sigma, inf = 0.06, 1e6
+    tq, ts, tt, tk = T(q), T(s), T(table), T(kpts)
+    weights = T((rng.standard_normal((k, c, d)) * 0.1).astype(np.float32)).requires_grad_(True)
+    bias = T(rng.standard_normal(d).astype(np.float32))
+    up = T(rng.standard_normal((m, d)).astype(np.float32))
+
+    f_ref = T(feats).requires_grad_(True)
+    padded_points = torch.cat([ts, torch.zeros_like(ts[:1]) + inf], 0)
+    neighbors = padded_points[tt] - tq.unsqueeze(1)
+    sq = ((neighbors.unsqueeze(2) - tk) ** 2).sum(dim=3)
+    nw = torch.clamp(1 - torch.sqrt(sq) / sigma, min=0.0).transpose(1, 2)
+    padded_feats = torch.cat([f_ref, torch.zeros_like(f_ref[:1])], 0)
+    nf = padded_feats[tt]
+    ref = torch.einsum("mkc,kcd->md", torch.matmul(nw, nf), weights)
+    num = torch.gt(nf.sum(dim=-1), 0.0).sum(dim=-1)
+    ref = ref / torch.max(num, torch.ones_like(num)).unsqueeze(1) + bias
+    ref.backward(up)
+    want_gf, want_gw = f_ref.grad.clone(), weights.grad.clone()
+    weights.grad = None
+
+    f = T(feats).requires_grad_(True)
+    got = ops.kpconv(tq, ts, f, tt, tk, weights, sigma, bias=bias)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5)
+    got.backward(up)
+    assert torch.allclose(f.grad, want_gf, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(weights.grad, want_gw, rtol=1e-4, atol=1e-5)
+    # shapes outside the fused kernel (C not a multiple of 4) keep working through the row-gather formulation
+    f5 = T(rng.standard_normal((n, 5)).astype(np.float32))
+    w5, n5 = ops.kpconv_gather(tq, ts, f5, tt, tk, sigma)
+    want5, num5, _ = oracle_mod.kpconv_gather(q, s, N_(f5), table, kpts, sigma)
+    assert np.allclose(N_(w5), want5, rtol=1e-4, atol=1e-5) and np.array_equal(N_(n5), num5)

@@ -201,6 +201,27 @@ def main():
             qe = qf.unsqueeze(3).expand_as(nb)
             return torch.cat([qe, nb - qe], dim=1)
         add(f"edge_group_threepass B{B} C{C} N{N} M{M} K{K}", three_pass_edge, by_ed, "GB/s")
+    # ---- KPConv aggregation: fused kernel vs the reference formulation in torch (kpconv.py:100-115) --------------------
+    for (n, h, c) in ((480000, 38, 64), (120000, 36, 128), (30000, 36, 256)):
+        s_pts = (torch.rand((n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
+        feats = torch.randn((n, c), generator=g).to(DEV)
+        near = (torch.arange(n).view(n, 1) + torch.randint(-2000, 2000, (n, h), generator=g)).clamp_(0, n).to(DEV)
+        kpts = (torch.randn((15, 3), generator=g) * 0.03).to(DEV)
+        wf = torch.empty((n, 15, c), device=DEV)
+        num = torch.empty((n,), dtype=torch.long, device=DEV)
+        flops = 2.0 * n * h * 15 * c / 1e6
+        add(f"kpconv_gather N{n} H{h} C{c}",
+            lambda s_pts=s_pts, feats=feats, near=near, kpts=kpts, wf=wf, num=num: ext.kpconv_gather(
+                s_pts, s_pts, feats, near, kpts, wf, num, 0.05), flops, "TFLOP/s")
+        if n <= 120000:
+            def torch_form(s_pts=s_pts, feats=feats, near=near, kpts=kpts):
+                pp = torch.cat([s_pts, torch.zeros_like(s_pts[:1]) + 1e6], 0)
+                nb = pp[near] - s_pts.unsqueeze(1)
+                sq = ((nb.unsqueeze(2) - kpts) ** 2).sum(dim=3)
+                nw = torch.clamp(1 - torch.sqrt(sq) / 0.05, min=0.0).transpose(1, 2)
+                nf = torch.cat([feats, torch.zeros_like(feats[:1])], 0)[near]
+                return torch.matmul(nw, nf), torch.gt(nf.sum(-1), 0).sum(-1)
+            add(f"kpconv_gather_torchref N{n} H{h} C{c}", torch_form, flops, "TFLOP/s")
     for name, fn, work, unit in cases:
         med, mn = timeit(fn)
         rate = (work / (med * 1e-3) / 1e6) if work else 0.0  # work/1e6 per second

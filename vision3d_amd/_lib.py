@@ -75,6 +75,10 @@ SIGNATURES = {
     "v3d_global_avgpool_pack_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int] + _TAIL),
     "v3d_sa_group_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_edge_group_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int] + _TAIL),
+    "v3d_kpconv_gather_workspace_bytes": (_c_size, [_c_i64]),
+    "v3d_kpconv_gather_f32": (
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_f32]
+        + _WS + _TAIL),
     "v3d_rows_csr_bytes": (_c_size, [_c_i64, _c_i64]),
     "v3d_rows_csr_build": (_c_int, [_c_ptr, _c_i64, _c_i64] + _WS + _TAIL),
     "v3d_rows_scatter_f32": (

@@ -1,0 +1,191 @@
+// kpconv.hip -- fused neighbourhood aggregation of KPConv ("fused gather + weighted sum").
+// The reference (vision3d/layers/kpconv.py:110-141) materialises, per layer:
+//   index_select(padded_points) (M,H,3) -> differences (M,H,K,3) -> sq_distances / neighbor_weights (M,H,K) ->
+//   index_select(padded_feats) (M,H,C) -> matmul(neighbor_weights^T, neighbor_feats) (M,K,C)  [M tiny GEMMs]
+//   -> sum(neighbor_feats, -1) > 0 -> neighbor_num (M,)
+// i.e. the (M,H,C) gather (4.7 GB at 480k points, 38 neighbours, 64 channels) and the (M,H,K,3) differences (3.3 GB)
+// go to HBM and come back.  Here one kernel produces weighted_feats (M,K,C) and neighbor_num (M,) from the inputs.
+//
+// Design (gfx950): one wave per query.  Lane l first owns neighbour l (index, offset from the query: one coalesced
+// index load and one point gather per query, H <= 64).  The kernel-point influences ARE the A operand of
+// v_mfma_f32_16x16x4_f32 (rows = 16 kernel points, k = 4 neighbours per step): lane l computes
+// A[l&15][l>>4] = max(0, 1 - |offset_h - kernel_point_kp| / sigma) in place, nothing is staged.  The B operand is the
+// gathered feature row read as ONE 16-byte load per lane (4 neighbours x 256 contiguous bytes per instruction); the four
+// floats of a lane feed four MFMAs whose column n stands for channel 4n + j, so the four accumulators of a lane are
+// again 4 consecutive channels and the result leaves as 16-byte stores, 256 contiguous bytes per kernel point.
+// Exact fp32 products (fp32-input MFMA); the sum over neighbours runs in the MFMA's order (like the reference's batched
+// GEMM, whose order is unspecified).
+#include <algorithm>
+
+#include "common.h"
+
+namespace v3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKpMaxNeighbors = 64;
+constexpr int kKpMaxKernelPoints = 16;
+constexpr int kKpSteps = kKpMaxNeighbors / 4;
+
+// rowsum[n] = sum_c feats[n,c]: the density normalisation counts neighbours whose feature SUM is positive (:137-138).
+__global__ __launch_bounds__(256) void kp_rowsum_kernel(const float4* __restrict__ feats, float* __restrict__ rowsum,
+                                                        int64_t N, int C4) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = lane; p < C4; p += 64) {
+    const float4 v = feats[n * C4 + p];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) rowsum[n] = s;
+}
+
+__global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_points,
+                                                            const float* __restrict__ s_points,
+                                                            const float4* __restrict__ feats,
+                                                            const int64_t* __restrict__ idx,
+                                                            const float* __restrict__ kernel_points,
+                                                            const float* __restrict__ rowsum,
+                                                            float4* __restrict__ out, int64_t* __restrict__ neighbor_num,
+                                                            int64_t M, int N, int H, int K, int C4, float sigma) {
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, grp = lane >> 4;
+  const int64_t waves = (int64_t)gridDim.x * 4;
+  const int S = (H + 3) >> 2;
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+  const bool kvalid = col < K;
+  if (kvalid) {
+    kx = kernel_points[col * 3 + 0];
+    ky = kernel_points[col * 3 + 1];
+    kz = kernel_points[col * 3 + 2];
+  }
+  const int chunks = (C4 + 15) >> 4;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += waves) {
+    // lane l owns neighbour l of this query
+    int row = -1;
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    if (lane < H) {
+      const int64_t i = idx[m * H + lane];
+      if (i >= 0 && i < N) {
+        row = (int)i;
+        ox = s_points[i * 3 + 0] - q_points[m * 3 + 0];  // :101-103
+        oy = s_points[i * 3 + 1] - q_points[m * 3 + 1];
+        oz = s_points[i * 3 + 2] - q_points[m * 3 + 2];
+      }
+    }
+    if (neighbor_num) {
+      const bool counted = row >= 0 && rowsum[row] > 0.f;             // :137-138
+      const int cnt = __builtin_popcountll(__ballot(counted));
+      if (lane == 0) neighbor_num[m] = cnt > 1 ? cnt : 1;              // :139
+    }
+    // A operand of every step (kernel point `col`, neighbour 4*st + grp) and the feature row it multiplies
+    float A[kKpSteps];
+    int rows[kKpSteps];
+#pragma unroll
+    for (int st = 0; st < kKpSteps; ++st) {
+      A[st] = 0.f;
+      rows[st] = -1;
+      if (st < S) {
+        const int h = 4 * st + grp;
+        const float nx = __shfl(ox, h, 64), ny = __shfl(oy, h, 64), nz = __shfl(oz, h, 64);
+        const int r = __shfl(row, h, 64);
+        const float dx = nx - kx, dy = ny - ky, dz = nz - kz;        // :106-107
+        const float sq = (dx * dx + dy * dy) + dz * dz;              // :108
+        const float w = fmaxf(1.f - sqrtf(sq) / sigma, 0.f);         // :109
+        rows[st] = r;
+        A[st] = (r >= 0 && kvalid) ? w : 0.f;                        // absent neighbours sit at `inf`: influence 0
+      }
+    }
+    for (int ch = 0; ch < chunks; ++ch) {
+      const int p = ch * 16 + col;
+      const bool pin = p < C4;
+      float4 Bv[kKpSteps];
+#pragma unroll
+      for (int st = 0; st < kKpSteps; ++st) {
+        Bv[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st < S && pin && rows[st] >= 0) Bv[st] = feats[(int64_t)rows[st] * C4 + p];   // :113-114
+      }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+#pragma unroll
+      for (int st = 0; st < kKpSteps; ++st) {
+        if (st < S) {                                                                      // :115
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], Bv[st].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], Bv[st].y, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], Bv[st].z, acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], Bv[st].w, acc3, 0, 0, 0);
+        }
+      }
+      if (pin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kp = grp * 4 + i;  // C/D layout: row = 4*(lane>>4) + register, column = lane & 15
+          if (kp < K) out[(m * K + kp) * C4 + p] = make_float4(acc0[i], acc1[i], acc2[i], acc3[i]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace v3d
+
+extern "C" {
+
+size_t v3d_kpconv_gather_workspace_bytes(int64_t N) { return N > 0 ? v3d::align_up(sizeof(float) * (size_t)N, 256) : 0; }
+
+int v3d_kpconv_gather_f32(const float* q_points, const float* s_points, const float* s_feats,
+                          const int64_t* neighbor_indices, const float* kernel_points, float* weighted_feats,
+                          int64_t* neighbor_num, int64_t M, int64_t N, int H, int K, int C, float sigma, void* workspace,
+                          size_t workspace_bytes, int device, void* stream_) {
+  using namespace v3d;
+  const char* what = "kpconv_gather";
+  V3D_REQUIRE(M >= 0 && N >= 0 && H >= 0 && K >= 0 && C >= 0, what, "negative dimension");
+  V3D_REQUIRE(H <= kKpMaxNeighbors, what, "at most 64 neighbours per query");
+  V3D_REQUIRE(K <= kKpMaxKernelPoints, what, "at most 16 kernel points");
+  V3D_REQUIRE(C % 4 == 0, what, "the channel count must be a multiple of 4 (16-byte row pieces)");
+  V3D_REQUIRE(sigma > 0.f, what, "sigma must be positive");
+  if (N >= (int64_t)INT32_MAX) {
+    set_last_error("%s: N must stay below 2^31", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  if (M == 0) return 0;
+  V3D_REQUIRE(q_points && (H == 0 || neighbor_indices) && (K == 0 || kernel_points) && (N == 0 || (s_points && s_feats)),
+              what, "null pointer");
+  V3D_REQUIRE(K == 0 || C == 0 || weighted_feats, what, "null pointer");
+  V3D_REQUIRE((((uintptr_t)s_feats | (uintptr_t)weighted_feats) & 15) == 0, what, "feature buffers must be 16-byte aligned");
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* rowsum = nullptr;
+  bool own = false;
+  if (neighbor_num && N > 0) {
+    const size_t need = v3d_kpconv_gather_workspace_bytes(N);
+    if (workspace == nullptr) {
+      V3D_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&rowsum), need, stream), what);
+      own = true;
+    } else if (workspace_bytes < need || ((uintptr_t)workspace & 15) != 0) {
+      set_last_error("%s: workspace needs %zu bytes (got %zu)", what, need, workspace_bytes);
+      return V3D_ERR_WORKSPACE;
+    } else {
+      rowsum = static_cast<float*>(workspace);
+    }
+    hipLaunchKernelGGL(kp_rowsum_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(s_feats), rowsum, N, C / 4);
+  }
+  const int64_t blocks = std::min<int64_t>(ceil_div(M, 4), 256 * 16);
+  hipLaunchKernelGGL(kpconv_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q_points, s_points,
+                     reinterpret_cast<const float4*>(s_feats), neighbor_indices, kernel_points, rowsum,
+                     reinterpret_cast<float4*>(weighted_feats), neighbor_num, M, (int)N, H, K, C / 4, sigma);
+  int rc = launch_status(what);
+  if (own) {
+    hipError_t e = hipFreeAsync(rowsum, stream);
+    if (rc == 0 && e != hipSuccess) {
+      set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
+      rc = (int)e;
+    }
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -42,6 +42,7 @@ __all__ = [
     "rows_scatter",
     "sa_group",
     "edge_group",
+    "kpconv_gather",
 ]
 
 _FLOATING = {torch.float32: "f32", torch.float64: "f64"}
@@ -604,3 +605,28 @@ def edge_group(q_feats, s_feats, indices, grouped):
     dev, stream = _where(s_feats)
     _lib.check(_lib.lib().v3d_edge_group_f32(q_feats.data_ptr(), s_feats.data_ptr(), indices.data_ptr(),
                                              grouped.data_ptr(), B, C, N, M, K, dev, stream), "edge_group")
+
+
+def kpconv_gather(q_points, s_points, s_feats, neighbor_indices, kernel_points, weighted_feats, neighbor_num, sigma):
+    """KPConv aggregation: weighted_feats (M,K,C) and (optional) neighbor_num (M,) int64; see include/v3d_hip.h."""
+    for t, n in ((q_points, "q_points"), (s_points, "s_points"), (s_feats, "s_feats"),
+                 (kernel_points, "kernel_points"), (weighted_feats, "weighted_feats")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(neighbor_indices, "neighbor_indices")
+    _check_long(neighbor_indices, "neighbor_indices")
+    if neighbor_num is not None:
+        _check_cuda_contiguous(neighbor_num, "neighbor_num")
+        _check_long(neighbor_num, "neighbor_num")
+    M, H = neighbor_indices.shape
+    N, C = s_feats.shape
+    K = kernel_points.shape[0]
+    if tuple(weighted_feats.shape) != (M, K, C) or q_points.shape[0] != M or s_points.shape[0] != N:
+        raise RuntimeError("kpconv_gather: expected q_points (M,3), s_points (N,3), weighted_feats (M,K,C)")
+    dev, stream = _where(s_feats)
+    ws = _workspace(_lib.lib().v3d_kpconv_gather_workspace_bytes(N), s_feats) if neighbor_num is not None else None
+    rc = _lib.lib().v3d_kpconv_gather_f32(
+        q_points.data_ptr(), s_points.data_ptr(), s_feats.data_ptr(), neighbor_indices.data_ptr(),
+        kernel_points.data_ptr(), weighted_feats.data_ptr(), _ptr(neighbor_num), M, N, H, K, C, float(sigma), _ptr(ws),
+        ws.numel() if ws is not None else 0, dev, stream)
+    _lib.check(rc, "kpconv_gather")

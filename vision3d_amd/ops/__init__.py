@@ -13,6 +13,7 @@ from .gather import gather
 from .group_gather import group_gather
 from .knn import knn, knn_pack_mode
 from .knn_points import knn_points
+from .kpconv import kpconv, kpconv_gather
 from .matching import extract_correspondences_from_feats
 from .mutual_topk_select import batch_mutual_topk_select, mutual_topk_select
 from .pack_gather import (global_avgpool_pack_mode, index_select, knn_interpolate_pack_mode,
@@ -29,5 +30,5 @@ __all__ = [
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats",
     "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
-    "knn_interpolate_pack_mode", "sa_group", "edge_group",
+    "knn_interpolate_pack_mode", "sa_group", "edge_group", "kpconv_gather", "kpconv",
 ]
