@@ -274,6 +274,21 @@ int v3d_kpconv_gather_f32(const float* q_points, const float* s_points, const fl
                           int64_t* neighbor_num, int64_t M, int64_t N, int H, int K, int C, float sigma, void* workspace,
                           size_t workspace_bytes, int device, void* stream);
 
+/* ---- point-to-node partition (vision3d/ops/point_cloud_partition.py:40-104) ------------------------
+ * points (N,3), nodes (M,3) fp32.  v3d_point_to_node_partition_f32: point_to_node (N) = nearest node of every point
+ * (exact squared differences, lowest node index on ties; the reference takes the argmin of its expanded-form distance
+ * matrix, :70-72), node_sizes (M) int64 (:75-79), node_masks (M) bool bytes (:82-84), *max_size = largest node size
+ * (device scalar; the reference reads it back with .item(), :91) -- each of the last three may be NULL.  `workspace`
+ * (v3d_point_to_node_workspace_bytes(N, M) bytes, 256-B aligned, REQUIRED) keeps the points ordered by (node, distance,
+ * index) for v3d_point_to_node_knn, which writes node_knn_indices (M,K) = the K nearest own points of every node,
+ * ascending, padded with N (:96-100), and node_knn_masks (M,K) (:99).  No (M,N) tensor is ever formed. */
+size_t v3d_point_to_node_workspace_bytes(int64_t N, int64_t M);
+int v3d_point_to_node_partition_f32(const float* points, const float* nodes, int64_t N, int64_t M,
+                                    int64_t* point_to_node, int64_t* node_sizes, uint8_t* node_masks, int64_t* max_size,
+                                    void* workspace, size_t workspace_bytes, int device, void* stream);
+int v3d_point_to_node_knn(const void* workspace, int64_t N, int64_t M, int K, int64_t* node_knn_indices,
+                          uint8_t* node_knn_masks, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,3 +187,31 @@ def kpconv_gather(q_points, s_points, s_feats, neighbor_indices, kernel_points, 
     weighted = np.matmul(w.astype(np.float64), neighbor_feats.astype(np.float64))              # :114
     num = (neighbor_feats.sum(axis=-1, dtype=np.float64) > 0).sum(axis=-1)                     # :137-138
     return weighted.astype(np.float32), np.maximum(num, 1).astype(np.int64), w
+
+
+# ---- point-to-node partition (ops/point_cloud_partition.py:40-104) ----------------------------------------------
+def point_to_node_partition(points, nodes, point_limit=None):
+    """(point_to_node (N,), node_sizes (M,), node_masks (M,), node_knn_indices (M,K), node_knn_masks (M,K)).
+
+    Follows the reference's steps (:70-102) with two stated definitions where it leaves room: squared distances are the
+    exact differences ((dx*dx + dy*dy) + dz*dz in float32) instead of the fp32 expansion of pairwise_distance, and
+    ties go to the lower node / point index (torch.min / torch.topk: unspecified).  PARITY UNPINNED: the module imports
+    pykeops at import time, so no reference-generated fixture exists; tests cross-check a torch restatement instead."""
+    p = np.asarray(points, dtype=np.float32)
+    nd = np.asarray(nodes, dtype=np.float32)
+    n, m = p.shape[0], nd.shape[0]
+    d = nd[:, None, :] - p[None, :, :]
+    sq = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]  # (M, N)   :70
+    point_to_node = np.argmin(sq, axis=0).astype(np.int64)                          # :72 (first minimum)
+    node_sizes = np.bincount(point_to_node, minlength=m).astype(np.int64)           # :76-78
+    node_masks = node_sizes > 0                                                     # :82-83
+    k = int(node_sizes.max())                                                       # :91
+    if point_limit is not None:
+        k = min(k, int(point_limit))                                                # :92-93
+    matching = np.zeros((m, n), dtype=bool)
+    matching[point_to_node, np.arange(n)] = True                                    # :86-88
+    masked = np.where(matching, sq, np.float32(np.inf))                             # :89
+    order = np.argsort(masked, axis=1, kind="stable")[:, :k]                        # :96
+    own = np.take_along_axis(matching, order, axis=1)                               # :97-99
+    knn = np.where(own, order, n).astype(np.int64)                                  # :100
+    return point_to_node, node_sizes, node_masks, knn, own

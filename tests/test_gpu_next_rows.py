@@ -380,3 +380,70 @@ def test_kpconv_layer_forward_backward_matches_reference_formulation(ext, oracle
     w5, n5 = ops.kpconv_gather(tq, ts, f5, tt, tk, sigma)
     want5, num5, _ = oracle_mod.kpconv_gather(q, s, N_(f5), table, kpts, sigma)
     assert np.allclose(N_(w5), want5, rtol=1e-4, atol=1e-5) and np.array_equal(N_(n5), num5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# point-to-node partition
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,limit", [(1, 1, None), (500, 7, None), (3000, 64, 128), (5000, 200, 16), (2000, 1500, 4),
+                                       (4096, 33, 64)])
+def test_point_to_node_partition_vs_oracle(ext, oracle_mod, n, m, limit):
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(n + m)
+    points = rng.random((n, 3), dtype=np.float32)
+    nodes = points[rng.permutation(n)[:m]] + (0.01 * rng.standard_normal((m, 3))).astype(np.float32) if m <= n else \
+        rng.random((m, 3), dtype=np.float32)
+    if n >= 500:  # exact ties: duplicated points (equal distances inside a node) and a duplicated node
+        points[10:20] = points[0:10]
+        if m > 3:
+            nodes[3] = nodes[2]
+    p2n, sizes, masks, knn, kmask = oracle_mod.point_to_node_partition(points, nodes, limit)
+    got = ops.point_to_node_partition(T(points), T(nodes), point_limit=limit, return_count=True)
+    assert len(got) == 5
+    assert np.array_equal(N_(got[0]), p2n) and np.array_equal(N_(got[1]), sizes) and np.array_equal(N_(got[2]), masks)
+    assert got[3].dtype == torch.long and got[4].dtype == torch.bool
+    assert np.array_equal(N_(got[3]), knn) and np.array_equal(N_(got[4]), kmask)
+    only = ops.point_to_node_partition(T(points), T(nodes), gather_points=False)
+    assert len(only) == 1 and np.array_equal(N_(only[0]), p2n)
+
+
+def test_point_to_node_partition_matches_reference_formulation(ext):
+    """The reference's own steps (point_cloud_partition.py:70-102) in torch on the same device; compared where the
+    assignment is unambiguous at the expansion's rounding error (margin between the two nearest nodes > 1e-5)."""
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(9)
+    n, m, limit = 4000, 96, 48
+    points = T(rng.random((n, 3), dtype=np.float32))
+    nodes = T(rng.random((m, 3), dtype=np.float32))
+    sq = ops.pairwise_distance(nodes, points)
+    p2n = sq.min(dim=0)[1]
+    two = sq.topk(k=2, dim=0, largest=False)[0]
+    clear = (two[1] - two[0]) > 1e-5
+    got_p2n, got_masks, got_knn, got_kmask = ops.point_to_node_partition(points, nodes, point_limit=limit)
+    assert torch.equal(got_p2n[clear], p2n[clear]) and clear.float().mean() > 0.99
+    if bool(clear.all()):
+        matching = torch.zeros_like(sq, dtype=torch.bool)
+        matching[p2n, torch.arange(n, device=DEV)] = True
+        k = min(int(matching.sum(dim=1).max()), limit)
+        knn = sq.masked_fill(~matching, 1e12).topk(k=k, dim=1, largest=False)[1]
+        kmask = p2n[knn] == torch.arange(m, device=DEV).unsqueeze(1)
+        knn = knn.masked_fill(~kmask, n)
+        assert torch.equal(got_kmask, kmask)
+        # same point sets per node; order may differ only between points whose distances agree to 1e-6
+        assert torch.equal(got_knn.sort(dim=1)[0], knn.sort(dim=1)[0])
+
+
+def test_ball_query_partition_contract(ext):
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(10)
+    points = T(rng.random((1500, 3), dtype=np.float32))
+    nodes = T(rng.random((40, 3), dtype=np.float32))
+    idx, masks, node_masks, sizes = ops.ball_query_partition(points, nodes, 0.1, 32, return_count=True)
+    d = torch.cdist(nodes, points)
+    assert idx.shape == (40, 32) and torch.equal(sizes, masks.sum(1)) and torch.equal(node_masks, sizes > 0)
+    assert torch.all(idx[~masks] == 1500)
+    want = torch.minimum((d < 0.1).sum(1), torch.tensor(32, device=DEV))
+    assert torch.equal(sizes, want)

@@ -43,6 +43,8 @@ __all__ = [
     "sa_group",
     "edge_group",
     "kpconv_gather",
+    "point_to_node_partition",
+    "point_to_node_knn",
 ]
 
 _FLOATING = {torch.float32: "f32", torch.float64: "f64"}
@@ -630,3 +632,38 @@ def kpconv_gather(q_points, s_points, s_feats, neighbor_indices, kernel_points, 
         kernel_points.data_ptr(), weighted_feats.data_ptr(), _ptr(neighbor_num), M, N, H, K, C, float(sigma), _ptr(ws),
         ws.numel() if ws is not None else 0, dev, stream)
     _lib.check(rc, "kpconv_gather")
+
+
+def point_to_node_partition(points, nodes, point_to_node, node_sizes=None, node_masks=None, max_size=None):
+    """points (N,3), nodes (M,3) fp32 -> point_to_node (N) int64 [+ node_sizes (M) int64, node_masks (M) bool, max_size ()].
+    Returns the workspace that ``point_to_node_knn`` consumes."""
+    for t, n in ((points, "points"), (nodes, "nodes")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    for t, n in ((point_to_node, "point_to_node"), (node_sizes, "node_sizes"), (max_size, "max_size")):
+        if t is not None:
+            _check_cuda_contiguous(t, n)
+            _check_long(t, n)
+    if node_masks is not None:
+        _check_cuda_contiguous(node_masks, "node_masks")
+        _check_bool(node_masks, "node_masks")
+    N, M = points.shape[0], nodes.shape[0]
+    ws = _workspace(_lib.lib().v3d_point_to_node_workspace_bytes(N, M), points)
+    dev, stream = _where(points)
+    _lib.check(_lib.lib().v3d_point_to_node_partition_f32(
+        points.data_ptr(), nodes.data_ptr(), N, M, point_to_node.data_ptr(), _ptr(node_sizes), _ptr(node_masks),
+        _ptr(max_size), ws.data_ptr(), ws.numel(), dev, stream), "point_to_node_partition")
+    return ws
+
+
+def point_to_node_knn(workspace, num_points, node_knn_indices, node_knn_masks=None):
+    """node_knn_indices (M,K) int64 / node_knn_masks (M,K) bool from the workspace of ``point_to_node_partition``."""
+    _check_cuda_contiguous(node_knn_indices, "node_knn_indices")
+    _check_long(node_knn_indices, "node_knn_indices")
+    if node_knn_masks is not None:
+        _check_cuda_contiguous(node_knn_masks, "node_knn_masks")
+        _check_bool(node_knn_masks, "node_knn_masks")
+    M, K = node_knn_indices.shape
+    dev, stream = _where(node_knn_indices)
+    _lib.check(_lib.lib().v3d_point_to_node_knn(workspace.data_ptr(), int(num_points), M, K, node_knn_indices.data_ptr(),
+                                                _ptr(node_knn_masks), dev, stream), "point_to_node_partition")

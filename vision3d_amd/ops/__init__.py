@@ -20,6 +20,7 @@ from .pack_gather import (global_avgpool_pack_mode, index_select, knn_interpolat
                           local_maxpool_pack_mode, nearest_interpolate_pack_mode)
 from .pairwise_distance import pairwise_distance
 from .grid_subsample import grid_subsample_pack_mode
+from .point_cloud_partition import ball_query_partition, point_to_node_partition
 from .radius_search import radius_count_pack_mode, radius_search_pack_mode
 from .three_interpolate import three_interpolate
 from .three_nn import three_nn
@@ -30,5 +31,5 @@ __all__ = [
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats",
     "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
-    "knn_interpolate_pack_mode", "sa_group", "edge_group", "kpconv_gather", "kpconv",
+    "knn_interpolate_pack_mode", "sa_group", "edge_group", "kpconv_gather", "kpconv", "point_to_node_partition", "ball_query_partition",
 ]
