@@ -25,7 +25,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKpMaxNeighbors = 64;
 constexpr int kKpMaxKernelPoints = 16;
-constexpr int kKpSteps = kKpMaxNeighbors / 4;
 
 // rowsum[n] = sum_c feats[n,c]: the density normalisation counts neighbours whose feature SUM is positive (:137-138).
 __global__ __launch_bounds__(256) void kp_rowsum_kernel(const float4* __restrict__ feats, float* __restrict__ rowsum,
@@ -42,6 +41,10 @@ __global__ __launch_bounds__(256) void kp_rowsum_kernel(const float4* __restrict
   if (lane == 0) rowsum[n] = s;
 }
 
+// MAXS = ceil(H / 4) rounded up to 8, 12 or 16 steps (sizes the register arrays: 4 waves per SIMD up to H = 48).
+// The grid-stride loop over queries is software-pipelined: the neighbour indices of the query two strides ahead and
+// the point gather of the query one stride ahead are in flight while the current query multiplies.
+template <int MAXS>
 __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restrict__ q_points,
                                                             const float* __restrict__ s_points,
                                                             const float4* __restrict__ feats,
@@ -62,54 +65,72 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
     kz = kernel_points[col * 3 + 2];
   }
   const int chunks = (C4 + 15) >> 4;
-  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += waves) {
-    // lane l owns neighbour l of this query
-    int row = -1;
-    float ox = 0.f, oy = 0.f, oz = 0.f;
-    if (lane < H) {
-      const int64_t i = idx[m * H + lane];
-      if (i >= 0 && i < N) {
-        row = (int)i;
-        ox = s_points[i * 3 + 0] - q_points[m * 3 + 0];  // :101-103
-        oy = s_points[i * 3 + 1] - q_points[m * 3 + 1];
-        oz = s_points[i * 3 + 2] - q_points[m * 3 + 2];
-      }
+  const int64_t m0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  auto load_index = [&](int64_t m) -> int {  // lane l owns neighbour l of query m; -1 = none
+    if (m >= M || lane >= H) return -1;
+    const int64_t i = idx[m * H + lane];
+    return (i >= 0 && i < N) ? (int)i : -1;
+  };
+  // stage 1 of query m0, stage 0 of query m0 + waves
+  int row = load_index(m0);
+  int row_next = load_index(m0 + waves);
+  float sx = 0.f, sy = 0.f, sz = 0.f, cnt_sum = 0.f;
+  auto load_point = [&](int r) {
+    sx = sy = sz = cnt_sum = 0.f;
+    if (r >= 0) {
+      sx = s_points[(int64_t)r * 3 + 0];
+      sy = s_points[(int64_t)r * 3 + 1];
+      sz = s_points[(int64_t)r * 3 + 2];
+      if (rowsum) cnt_sum = rowsum[r];
     }
+  };
+  load_point(row);
+  for (int64_t m = m0; m < M; m += waves) {
+    // this query's operands (requested one stride ago) ...
+    const int cur_row = row;
+    const float qx = q_points[m * 3 + 0], qy = q_points[m * 3 + 1], qz = q_points[m * 3 + 2];
+    const float ox = sx - qx, oy = sy - qy, oz = sz - qz;             // :101-103
+    const bool counted = cur_row >= 0 && cnt_sum > 0.f;               // :137-138
+    // ... and the next queries' requests
+    row = row_next;
+    row_next = load_index(m + 2 * waves);
+    load_point(row);
     if (neighbor_num) {
-      const bool counted = row >= 0 && rowsum[row] > 0.f;             // :137-138
       const int cnt = __builtin_popcountll(__ballot(counted));
-      if (lane == 0) neighbor_num[m] = cnt > 1 ? cnt : 1;              // :139
+      if (lane == 0) neighbor_num[m] = cnt > 1 ? cnt : 1;             // :139
     }
-    // A operand of every step (kernel point `col`, neighbour 4*st + grp) and the feature row it multiplies
-    float A[kKpSteps];
-    int rows[kKpSteps];
+    // A operand of every step: kernel point `col`, neighbour 4*st + grp
+    float A[MAXS];
 #pragma unroll
-    for (int st = 0; st < kKpSteps; ++st) {
+    for (int st = 0; st < MAXS; ++st) {
       A[st] = 0.f;
-      rows[st] = -1;
       if (st < S) {
         const int h = 4 * st + grp;
         const float nx = __shfl(ox, h, 64), ny = __shfl(oy, h, 64), nz = __shfl(oz, h, 64);
-        const int r = __shfl(row, h, 64);
+        const int r = __shfl(cur_row, h, 64);
         const float dx = nx - kx, dy = ny - ky, dz = nz - kz;        // :106-107
         const float sq = (dx * dx + dy * dy) + dz * dz;              // :108
-        const float w = fmaxf(1.f - sqrtf(sq) / sigma, 0.f);         // :109
-        rows[st] = r;
+        // :109 -- correctly rounded sqrt and division like the reference (a hardware sqrt * (1/sigma) was measured:
+        // 5 % faster, but the influence loses its last bits next to the clamp, where 1 - x cancels)
+        const float w = fmaxf(1.f - sqrtf(sq) / sigma, 0.f);
         A[st] = (r >= 0 && kvalid) ? w : 0.f;                        // absent neighbours sit at `inf`: influence 0
       }
     }
     for (int ch = 0; ch < chunks; ++ch) {
       const int p = ch * 16 + col;
       const bool pin = p < C4;
-      float4 Bv[kKpSteps];
+      float4 Bv[MAXS];
 #pragma unroll
-      for (int st = 0; st < kKpSteps; ++st) {
+      for (int st = 0; st < MAXS; ++st) {
         Bv[st] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (st < S && pin && rows[st] >= 0) Bv[st] = feats[(int64_t)rows[st] * C4 + p];   // :113-114
+        if (st < S) {
+          const int r = __shfl(cur_row, 4 * st + grp, 64);
+          if (pin && r >= 0) Bv[st] = feats[(int64_t)r * C4 + p];   // :113-114
+        }
       }
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
 #pragma unroll
-      for (int st = 0; st < kKpSteps; ++st) {
+      for (int st = 0; st < MAXS; ++st) {
         if (st < S) {                                                                      // :115
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], Bv[st].x, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], Bv[st].y, acc1, 0, 0, 0);
@@ -173,10 +194,16 @@ int v3d_kpconv_gather_f32(const float* q_points, const float* s_points, const fl
     hipLaunchKernelGGL(kp_rowsum_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, stream,
                        reinterpret_cast<const float4*>(s_feats), rowsum, N, C / 4);
   }
-  const int64_t blocks = std::min<int64_t>(ceil_div(M, 4), 256 * 16);
-  hipLaunchKernelGGL(kpconv_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q_points, s_points,
-                     reinterpret_cast<const float4*>(s_feats), neighbor_indices, kernel_points, rowsum,
-                     reinterpret_cast<float4*>(weighted_feats), neighbor_num, M, (int)N, H, K, C / 4, sigma);
+  // resident grid (4 workgroups of 4 waves per CU): every wave walks its queries with the pipeline above
+  const int64_t blocks = std::min<int64_t>(ceil_div(M, 4), 256 * 4);
+#define V3D_KP_LAUNCH(MAXS_)                                                                                         \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(kpconv_gather_kernel<MAXS_>), dim3((unsigned)blocks), dim3(256), 0, stream,    \
+                     q_points, s_points, reinterpret_cast<const float4*>(s_feats), neighbor_indices, kernel_points, \
+                     rowsum, reinterpret_cast<float4*>(weighted_feats), neighbor_num, M, (int)N, H, K, C / 4, sigma)
+  if (H <= 32) V3D_KP_LAUNCH(8);
+  else if (H <= 48) V3D_KP_LAUNCH(12);
+  else V3D_KP_LAUNCH(16);
+#undef V3D_KP_LAUNCH
   int rc = launch_status(what);
   if (own) {
     hipError_t e = hipFreeAsync(rowsum, stream);

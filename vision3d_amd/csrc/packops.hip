@@ -45,6 +45,13 @@ __device__ __forceinline__ unsigned zero_of<unsigned>() { return 0u; }
 template <>
 __device__ __forceinline__ unsigned char zero_of<unsigned char>() { return 0; }
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(uint4* dst, const uint4& v) {
+  __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(dst));
+}
+__device__ __forceinline__ void store_stream(unsigned* dst, const unsigned& v) { __builtin_nontemporal_store(v, dst); }
+__device__ __forceinline__ void store_stream(unsigned char* dst, const unsigned char& v) { *dst = v; }
+
 // out[l, :] = src[idx[l * idx_stride], :] (zeros when the index is outside [0, N)).  Lanes: (row in wave, piece).
 template <typename V>
 __global__ __launch_bounds__(256) void rows_gather_kernel(const V* __restrict__ src, const int64_t* __restrict__ idx,
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const V* __restrict__ 
   const int rows_per_wave = 64 >> rs.sub_shift;
   const int sub = lane >> rs.sub_shift, p0 = lane & ((1 << rs.sub_shift) - 1);
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  constexpr int U = 4;  // row groups in flight per wave
+  constexpr int U = 8;  // row groups in flight per wave
   const int64_t l0 = wave * (int64_t)(rows_per_wave * U) + sub;
   int64_t src_row[U];
 #pragma unroll
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const V* __restrict__ 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t l = l0 + (int64_t)u * rows_per_wave;
-      if (l < L) out[l * rs.pieces + p] = v[u];
+      if (l < L) store_stream(&out[l * rs.pieces + p], v[u]);  // written once, never re-read here
     }
   }
 }
@@ -344,17 +351,17 @@ int v3d_index_select_rows(const void* sources, const int64_t* indices, int64_t i
   const uintptr_t both = (uintptr_t)sources | (uintptr_t)targets;
   if (row_bytes % 16 == 0 && both % 16 == 0) {
     const RowShape rs = row_shape(row_bytes / 16);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rows_gather_kernel<uint4>), dim3(row_blocks(L, rs, 4)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rows_gather_kernel<uint4>), dim3(row_blocks(L, rs, 8)), dim3(256), 0, stream,
                        static_cast<const uint4*>(sources), indices, index_stride, static_cast<uint4*>(targets), L, (int)N,
                        rs);
   } else if (row_bytes % 4 == 0 && both % 4 == 0) {
     const RowShape rs = row_shape(row_bytes / 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rows_gather_kernel<unsigned>), dim3(row_blocks(L, rs, 4)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rows_gather_kernel<unsigned>), dim3(row_blocks(L, rs, 8)), dim3(256), 0, stream,
                        static_cast<const unsigned*>(sources), indices, index_stride, static_cast<unsigned*>(targets), L,
                        (int)N, rs);
   } else {
     const RowShape rs = row_shape(row_bytes);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rows_gather_kernel<unsigned char>), dim3(row_blocks(L, rs, 4)), dim3(256), 0,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rows_gather_kernel<unsigned char>), dim3(row_blocks(L, rs, 8)), dim3(256), 0,
                        stream, static_cast<const unsigned char*>(sources), indices, index_stride,
                        static_cast<unsigned char*>(targets), L, (int)N, rs);
   }
