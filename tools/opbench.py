@@ -148,7 +148,7 @@ def main():
         feats = torch.randn((n, c), generator=g).to(DEV)
         table = torch.randint(0, n + 1, (n, k), generator=g).to(DEV)
         # neighbours of a point are near it in memory after grid subsampling: indices within +-2000 rows
-        near = (torch.arange(n).view(n, 1) + torch.randint(-2000, 2000, (n, k), generator=g)).clamp_(0, n).to(DEV)
+        near = ((torch.arange(n).view(n, 1) + torch.randint(-2000, 2000, (n, k), generator=g)) % n).to(DEV)
         out3 = torch.empty((n, k, c), device=DEV)
         out2 = torch.empty((n, c), device=DEV)
         argk = torch.empty((n, c), dtype=torch.uint8, device=DEV)
@@ -205,7 +205,7 @@ def main():
     for (n, h, c) in ((480000, 38, 64), (120000, 36, 128), (30000, 36, 256)):
         s_pts = (torch.rand((n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
         feats = torch.randn((n, c), generator=g).to(DEV)
-        near = (torch.arange(n).view(n, 1) + torch.randint(-2000, 2000, (n, h), generator=g)).clamp_(0, n).to(DEV)
+        near = ((torch.arange(n).view(n, 1) + torch.randint(-2000, 2000, (n, h), generator=g)) % n).to(DEV)
         kpts = (torch.randn((15, 3), generator=g) * 0.03).to(DEV)
         wf = torch.empty((n, 15, c), device=DEV)
         num = torch.empty((n,), dtype=torch.long, device=DEV)
