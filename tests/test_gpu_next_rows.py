@@ -447,3 +447,128 @@ def test_ball_query_partition_contract(ext):
     assert torch.all(idx[~masks] == 1500)
     want = torch.minimum((d < 0.1).sum(1), torch.tensor(32, device=DEV))
     assert torch.equal(sizes, want)
+
+
+# ------------------------------------------------------------------------------------------------------
+# full BASELINE sizes (configs C2 / C4 / C5) -- checked on the device against independent torch formulations and through
+# size-independent properties, since the CPU oracle does not finish in seconds there
+# ------------------------------------------------------------------------------------------------------
+def test_full_size_c5_mutual_matching_properties(ext):
+    """100k x 100k descriptors, C = 256 (BASELINE config 5): mutual nearest neighbours without the 40 GB matrix."""
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    n = m = 100000
+    x = torch.nn.functional.normalize(torch.randn((n, 256), generator=g), dim=1).to(DEV)
+    y = torch.nn.functional.normalize(torch.randn((m, 256), generator=g), dim=1).to(DEV)
+    y[:30000] = torch.nn.functional.normalize(x[:30000] + 0.02 * torch.randn((30000, 256), generator=g).to(DEV), dim=1)
+    row_d = torch.empty((1, n, 1), device=DEV)
+    row_i = torch.empty((1, n, 1), dtype=torch.long, device=DEV)
+    col_d = torch.empty((1, m, 1), device=DEV)
+    col_i = torch.empty((1, m, 1), dtype=torch.long, device=DEV)
+    ext.knn_feat(x.unsqueeze(0), y.unsqueeze(0), row_d, row_i, 1)
+    ext.knn_feat(y.unsqueeze(0), x.unsqueeze(0), col_d, col_i, 1)
+    r, c, d = ops.extract_correspondences_from_feats(x, y, mutual=True, return_feat_dist=True)
+    ri, ci = row_i.view(-1), col_i.view(-1)
+    # definition: (r, c) is kept iff c is r's nearest column and r is c's nearest row; nonzero order; planted pairs found
+    assert torch.equal(ri[r], c) and torch.equal(ci[c], r)
+    keep = ci[ri] == torch.arange(n, device=DEV)
+    assert r.numel() == int(keep.sum()) and torch.equal(r, torch.nonzero(keep).view(-1))
+    assert int((r < 30000).sum()) >= 29990 and torch.equal(c[r < 30000], r[r < 30000])
+    exact = ((x[r] - y[c]) ** 2).sum(dim=1)
+    assert torch.allclose(d, exact, atol=2e-5, rtol=0)
+    # union: every row and every column appears; pairs are unique and sorted by (row, col)
+    r2, c2 = ops.extract_correspondences_from_feats(x, y, mutual=False)
+    key = r2 * m + c2
+    assert torch.all(key[1:] > key[:-1])
+    assert torch.unique(r2).numel() == n and torch.unique(c2).numel() == m
+    assert r2.numel() == n + m - r.numel()
+
+
+def test_full_size_c4_pack_gathers_against_torch(ext):
+    """One KPConv pyramid stage of BASELINE config 4: 16 clouds x 30,000 points, 38 neighbours, 64 channels."""
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    n, k, c = 480000, 38, 64
+    feats = torch.randn((n, c), generator=g).to(DEV)
+    table = ((torch.arange(n).view(n, 1) + torch.randint(-3000, 3000, (n, k), generator=g)) % n)
+    table[torch.rand((n, k), generator=g) < 0.15] = n
+    table = table.to(DEV)
+    padded = torch.cat([feats, torch.zeros_like(feats[:1])], 0)
+    gathered = padded[table]  # (n, k, c): the reference's intermediate, 4.7 GB
+    assert torch.equal(ops.index_select(feats, table, dim=0), gathered)
+    assert torch.equal(ops.local_maxpool_pack_mode(feats, table), gathered.max(1)[0])
+    assert torch.equal(ops.nearest_interpolate_pack_mode(feats, table), gathered[:, 0])
+    pts = (torch.rand((n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
+    got = ops.knn_interpolate_pack_mode(pts, pts, feats, table, k=3)
+    t3 = table[:, :3]
+    ppad = torch.cat([pts, torch.zeros_like(pts[:1])], 0)
+    sq = (pts.unsqueeze(1) - ppad[t3]).pow(2).sum(dim=-1)
+    w = (t3 != n).float() / (sq + 1e-8)
+    w = w / (w.sum(dim=1, keepdim=True) + 1e-8)
+    want = (gathered[:, :3] * w.unsqueeze(-1)).sum(dim=1)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(feats.abs().max()))
+    lengths = torch.full((16,), 30000, dtype=torch.long, device=DEV)
+    pooled = ops.global_avgpool_pack_mode(feats, lengths)
+    assert torch.allclose(pooled, feats.view(16, 30000, c).mean(dim=1), atol=1e-5 * float(feats.abs().max()), rtol=0)
+    # backward of the gather: linear in the upstream gradient and equal to torch's index_add_ up to summation order
+    del gathered
+    up = torch.randn((n, c), generator=g).to(DEV)
+    f = feats.clone().requires_grad_(True)
+    ops.local_maxpool_pack_mode(f, table).backward(up)
+    f2 = feats.clone().requires_grad_(True)
+    torch.cat([f2, torch.zeros_like(f2[:1])], 0)[table].max(1)[0].backward(up)
+    assert torch.allclose(f.grad, f2.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_c2_fused_grouping_equals_three_pass(ext):
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    b, c, n, m, k = 32, 64, 4096, 1024, 128
+    s_points = torch.rand((b, 3, n), generator=g).to(DEV)
+    q_points = s_points[:, :, :m].contiguous()
+    s_feats = torch.randn((b, c, n), generator=g).to(DEV)
+    idx = torch.randint(0, n, (b, m, k), generator=g).to(DEV)
+    want = torch.cat([ops.group_gather(s_feats, idx), ops.group_gather(s_points, idx) - q_points.unsqueeze(3)], dim=1)
+    assert torch.equal(ops.sa_group(q_points, s_points, s_feats, idx), want)
+    # the plain group gather itself (now on the fused kernel) against torch's gather
+    ref = torch.gather(s_feats.unsqueeze(2).expand(-1, -1, m, -1), 3, idx.unsqueeze(1).expand(-1, c, -1, -1))
+    assert torch.equal(want[:, :c], ref)
+    q_feats = torch.randn((b, c, m), generator=g).to(DEV)
+    nb = ops.group_gather(s_feats, idx[:, :, :32].contiguous())
+    qe = q_feats.unsqueeze(3).expand_as(nb)
+    assert torch.equal(ops.edge_group(q_feats, s_feats, idx[:, :, :32].contiguous()), torch.cat([qe, nb - qe], dim=1))
+
+
+def test_full_size_kpconv_stage_against_torch_formulation(ext):
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(6)
+    n, h, c = 120000, 36, 128
+    pts = (torch.rand((n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
+    # neighbours that are actually near: sort by a space-filling key first so that index-near means space-near
+    order = torch.argsort((pts[:, 0] * 8).floor() * 10000 + (pts[:, 1] * 8).floor() * 100 + (pts[:, 2] * 8).floor())
+    pts = pts[order].contiguous()
+    feats = torch.randn((n, c), generator=g).to(DEV)
+    feats[torch.rand(n, generator=g).to(DEV) < 0.1] = 0.0
+    table = ((torch.arange(n).view(n, 1) + torch.randint(-40, 40, (n, h), generator=g)) % n)
+    table[torch.rand((n, h), generator=g) < 0.1] = n
+    table = table.to(DEV)
+    kpts = (torch.randn((15, 3), generator=g) * 0.05).to(DEV)
+    sigma = 0.08
+    weighted, num = ops.kpconv_gather(pts, pts, feats, table, kpts, sigma)
+    pp = torch.cat([pts, torch.zeros_like(pts[:1]) + 1e6], 0)
+    sq = ((pp[table] - pts.unsqueeze(1)).unsqueeze(2) - kpts).pow(2).sum(dim=3)
+    nw = torch.clamp(1 - torch.sqrt(sq) / sigma, min=0.0).transpose(1, 2)
+    nf = torch.cat([feats, torch.zeros_like(feats[:1])], 0)[table]
+    want = torch.matmul(nw, nf)
+    scale = torch.matmul(nw, nf.abs())
+    assert float(nw.max()) > 0.5  # the influences are not all clamped away
+    # 1e-5 of the summed magnitude, plus the influences' own rounding: torch evaluates 1 - sqrt(.)/sigma with its own
+    # sqrt / division, and next to the clamp that difference (<= 1e-6 absolute) is not relative to the influence
+    slack = 1e-6 * nf.abs().sum(dim=1).unsqueeze(1)
+    assert torch.all((weighted - want).abs() <= 1e-5 * scale + slack)
+    want_num = torch.gt(nf.sum(dim=-1), 0.0).sum(dim=-1).clamp_(min=1)
+    assert float((num != want_num).float().mean()) < 1e-4  # feature sums within rounding of zero may differ
