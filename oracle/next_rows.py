@@ -43,6 +43,22 @@ def mutual_topk_select(score_mat, k, **kw):
     return b.astype(np.int64), r.astype(np.int64), c.astype(np.int64), s[b, r, c]
 
 
+def extract_correspondences_from_scores(score_mat, mutual=False, has_dustbin=False, threshold=0.0):
+    """ops/matching.py:32-59: (rows, cols, exp scores) of the row / column maxima above the threshold."""
+    s = np.exp(np.asarray(score_mat, dtype=np.float32))                                  # :32
+    n, m = s.shape
+    row_mat = np.zeros_like(s)
+    row_mat[np.arange(n), s.argmax(axis=1)] = s.max(axis=1)                              # :35-38
+    col_mat = np.zeros_like(s)
+    col_mat[s.argmax(axis=0), np.arange(m)] = s.max(axis=0)                              # :41-44
+    thr = np.float32(threshold)
+    corr = (row_mat > thr) & (col_mat > thr) if mutual else (row_mat > thr) | (col_mat > thr)   # :39,:45,:47-50
+    if has_dustbin:
+        corr = corr[:-1, :-1]                                                            # :52-53
+    r, c = np.nonzero(corr)
+    return r.astype(np.int64), c.astype(np.int64), s[r, c]
+
+
 # ---- rank 3: pack-mode row gathers ------------------------------------------------------------------------------
 def _padded(feats):
     feats = np.asarray(feats)

@@ -118,6 +118,31 @@ def make_select_fixtures():
             bi, ri, ci, sc = mts.batch_mutual_topk_select(ts, k)
             out[f"{name}_reduced"] = np.stack([bi.numpy(), ri.numpy(), ci.numpy()])
             out[f"{name}_reduced_scores"] = sc.numpy()
+        # ops/matching.py (max selection on log-scores): loaded as a submodule of an empty synthetic parent package whose
+        # __path__ is the reference's ops directory, so that its relative imports resolve to the reference's own files
+        import importlib
+        import types
+
+        parent = types.ModuleType("v3dref_ops")
+        parent.__path__ = [os.path.join(REF, "ops")]
+        sys.modules["v3dref_ops"] = parent
+        try:
+            matching = importlib.import_module("v3dref_ops.matching")
+            logits = rng.standard_normal((41, 57)).astype(np.float32)
+            log_p = logits - np.log(np.exp(logits).sum(axis=1, keepdims=True))
+            out["m_log_p"] = log_p.astype(np.float32)
+            for mutual in (False, True):
+                for dustbin in (False, True):
+                    for thr in (0.0, 0.05):
+                        r_, c_, s_ = matching.extract_correspondences_from_scores(
+                            torch.from_numpy(out["m_log_p"]), mutual=mutual, has_dustbin=dustbin, threshold=thr,
+                            return_score=True)
+                        tag = f"m_m{int(mutual)}_d{int(dustbin)}_t{int(thr > 0)}"
+                        out[tag] = np.stack([r_.numpy(), c_.numpy()])
+                        out[tag + "_scores"] = s_.numpy()
+        finally:
+            for name in [k_ for k_ in sys.modules if k_.startswith("v3dref_ops")]:
+                del sys.modules[name]
         ri, ci, sc = mts.mutual_topk_select(torch.from_numpy(out["a_score"][0]), 3, largest=False, mutual=False)
         out["a2d_reduced"] = np.stack([ri.numpy(), ci.numpy()])
         out["a2d_reduced_scores"] = sc.numpy()

@@ -572,3 +572,32 @@ def test_full_size_kpconv_stage_against_torch_formulation(ext):
     assert torch.all((weighted - want).abs() <= 1e-5 * scale + slack)
     want_num = torch.gt(nf.sum(dim=-1), 0.0).sum(dim=-1).clamp_(min=1)
     assert float((num != want_num).float().mean()) < 1e-4  # feature sums within rounding of zero may differ
+
+
+def test_extract_correspondences_from_scores_vs_reference_fixture(ext, golden):
+    from vision3d_amd import ops
+
+    g = golden("ref_select.npz")
+    log_p = T(g["m_log_p"])
+    for mutual in (False, True):
+        for dustbin in (False, True):
+            for thr in (0.0, 0.05):
+                tag = f"m_m{int(mutual)}_d{int(dustbin)}_t{int(thr > 0)}"
+                r, c, s = ops.extract_correspondences_from_scores(log_p, mutual=mutual, has_dustbin=dustbin,
+                                                                  threshold=thr, return_score=True)
+                assert np.array_equal(np.stack([N_(r), N_(c)]), g[tag]), tag
+                assert np.allclose(N_(s), g[tag + "_scores"], rtol=1e-6), tag
+                assert len(ops.extract_correspondences_from_scores(log_p, mutual=mutual, has_dustbin=dustbin)) == 2
+
+
+def test_sharded_matching_default_kernels_single_rank(ext):
+    """sharding.mutual_matching_sharded with its default (HIP) search / merge / select on one rank == the ops route."""
+    from vision3d_amd import ops, sharding
+
+    rng = np.random.default_rng(31)
+    x = T(rng.standard_normal((700, 16)).astype(np.float32))
+    y = T(rng.standard_normal((900, 16)).astype(np.float32))
+    for mutual in (True, False):
+        r, c, d = sharding.mutual_matching_sharded(x, y, 1, 0, 900, mutual=mutual)
+        wr, wc, wd = ops.extract_correspondences_from_feats(x, y, mutual=mutual, return_feat_dist=True, normalized=False)
+        assert torch.equal(r, wr) and torch.equal(c, wc) and torch.allclose(d * d, wd)

@@ -76,3 +76,14 @@ def test_knn_interpolate_oracle_properties(oracle_mod):
     t2 = np.stack([np.arange(5), (np.arange(5) + 7) % 50], axis=1).astype(np.int64)
     out = oracle_mod.knn_interpolate_pack(q2, s, feats, t2)
     assert np.allclose(out, feats[:5], atol=1e-4)
+
+
+def test_extract_correspondences_from_scores_oracle_matches_reference_fixture(oracle_mod, golden):
+    g = golden("ref_select.npz")
+    for mutual in (False, True):
+        for dustbin in (False, True):
+            for thr in (0.0, 0.05):
+                tag = f"m_m{int(mutual)}_d{int(dustbin)}_t{int(thr > 0)}"
+                r, c, s = oracle_mod.extract_correspondences_from_scores(g["m_log_p"], mutual, dustbin, thr)
+                assert np.array_equal(np.stack([r, c]), g[tag]), tag
+                assert np.allclose(s, g[tag + "_scores"], rtol=1e-6), tag  # exp() of numpy vs torch: 1 ulp

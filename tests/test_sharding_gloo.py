@@ -43,6 +43,60 @@ def _np_merge(parts_d, parts_i):
     return torch.gather(d, 1, order), torch.gather(i, 1, order)
 
 
+def _np_select(row_i, row_d, col_i, col_d, mutual):
+    """NumPy stand-in of ext.mutual_select_lists (checked against the kernel in tests/test_gpu_next_rows.py)."""
+    n, m = row_i.shape[0], col_i.shape[0]
+    rows = torch.zeros((n, m), dtype=torch.bool)
+    cols = torch.zeros((n, m), dtype=torch.bool)
+    dmat = torch.zeros((n, m))
+    for r in range(n):
+        for j in range(row_i.shape[1]):
+            if row_i[r, j] >= 0:
+                rows[r, row_i[r, j]] = True
+                dmat[r, row_i[r, j]] = row_d[r, j]
+    for c in range(m):
+        for j in range(col_i.shape[1]):
+            if col_i[c, j] >= 0:
+                cols[col_i[c, j], c] = True
+                dmat[col_i[c, j], c] = col_d[c, j]
+    corr = (rows & cols) if mutual else (rows | cols)
+    r, c = torch.nonzero(corr, as_tuple=True)
+    return r, c, dmat[r, c]
+
+
+def _matching_worker(rank, world, port, n_ref, k, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(1)
+        q = torch.randn(30, 6, generator=g)
+        refs = torch.cat([q[:12] + 0.01 * torch.randn(12, 6, generator=g), torch.randn(n_ref - 12, 6, generator=g)])
+        b, e = sharding.batch_bounds(n_ref, world, rank)
+        ok = True
+        for mutual in (True, False):
+            got = sharding.mutual_matching_sharded(q, refs[b:e], k, b, n_ref, mutual=mutual, search_fn=_np_search,
+                                                   merge_fn=_np_merge, select_fn=_np_select)
+            rd, ri = _np_search(q, refs, k, 0)
+            cd, ci = _np_search(refs, q, k, 0)
+            want = _np_select(ri, rd, ci, cd, mutual)
+            ok = ok and all(torch.equal(a, w) if a.dtype == torch.long else torch.allclose(a, w)
+                            for a, w in zip(got, want))
+            if mutual:  # the planted pairs are found
+                ok = ok and int((got[0] < 12).sum()) >= 12
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_ref,k", [(2, 41, 1), (2, 40, 2), (3, 31, 1)])
+def test_sharded_mutual_matching_equals_single_shot(world, n_ref, k):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_matching_worker, args=(world, port, n_ref, k, out), nprocs=world, join=True)
+        assert all(out.get(r) for r in range(world)), dict(out)
+
+
 def _worker(rank, world, port, n_ref, k, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

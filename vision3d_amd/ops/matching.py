@@ -10,6 +10,31 @@ import torch
 from torch import Tensor
 
 from .. import ext
+from .mutual_topk_select import mutual_topk_select
+
+
+@torch.no_grad()
+def extract_correspondences_from_scores(
+    score_mat: Tensor,
+    mutual: bool = False,
+    has_dustbin: bool = False,
+    threshold: float = 0.0,
+    return_score: bool = False,
+):
+    """Max selection on a log-probability matrix (matching.py:10-61): entries that are the maximum of their row and /
+    or of their column with ``exp(score) > threshold``; (N+1, M+1) matrices with a dustbin drop their last row / column.
+
+    One elementwise ``exp`` plus the native selection (``ext.mutual_topk_select``, k = 1) replace the reference's two
+    ``torch.max``, four matrix-sized scatters / comparisons and ``nonzero``.
+    """
+    score_mat = torch.exp(score_mat)  # :32
+    rows, cols, scores = mutual_topk_select(score_mat, 1, largest=True, threshold=threshold, mutual=mutual)
+    if has_dustbin:  # :52-53
+        keep = (rows != score_mat.shape[0] - 1) & (cols != score_mat.shape[1] - 1)
+        rows, cols, scores = rows[keep], cols[keep], scores[keep]
+    if return_score:
+        return rows, cols, scores
+    return rows, cols
 
 
 @torch.no_grad()

@@ -81,6 +81,22 @@ def knn_reference_sharded(
     return merge_fn(all_d.view(world, rows, k), all_i.view(world, rows, k))
 
 
+def _hip_select(row_i, row_d, col_i, col_d, mutual):
+    from . import ext
+
+    n, k = row_i.shape
+    m = col_i.shape[0]
+    bound = max(k * (min(n, m) if mutual else n + m), 1)
+    idx = torch.empty((2, bound), dtype=torch.long, device=row_i.device)
+    dist_ = torch.empty((bound,), dtype=torch.float32, device=row_i.device)
+    count = torch.zeros((), dtype=torch.long, device=row_i.device)
+    ext.mutual_select_lists(row_i.unsqueeze(0).contiguous(), row_d.unsqueeze(0).contiguous(),
+                            col_i.unsqueeze(0).contiguous(), col_d.unsqueeze(0).contiguous(), m, out_row=idx[0],
+                            out_col=idx[1], out_score=dist_, num_out=count, largest=False, mutual=mutual)
+    c = int(count.item())
+    return idx[0, :c], idx[1, :c], dist_[:c]
+
+
 def mutual_topk_reference_sharded(queries, local_refs, k, ref_offset, group=None, search_fn=_hip_search,
                                   merge_fn=_hip_merge):
     """Row side of ops/mutual_topk_select.py:33 under reference-set sharding: see knn_reference_sharded.  The column
@@ -88,3 +104,34 @@ def mutual_topk_reference_sharded(queries, local_refs, k, ref_offset, group=None
     row = knn_reference_sharded(queries, local_refs, k, ref_offset, group, search_fn, merge_fn)
     col = search_fn(local_refs, queries, k, 0)
     return row, col
+
+
+def mutual_matching_sharded(queries, local_refs, k, ref_offset, num_refs_total, mutual=True, group=None,
+                            search_fn=_hip_search, merge_fn=_hip_merge, select_fn=_hip_select):
+    """Mutual (or union) top-k matching of ``queries`` against a reference set partitioned across ranks -- BASELINE
+    config 5 on a node: (query indices, global reference indices, distances), identical on every rank and identical to
+    the single-device ``ops.extract_correspondences_from_feats`` / ``mutual_topk_select`` result.
+
+    Exchange steps: the all-gather of the (N_q, k) partial row lists inside ``knn_reference_sharded`` and ONE all-gather
+    of the column lists (every rank owns the complete top-k of ITS references, so they are concatenated, not merged:
+    12 * k bytes per reference).  Blocks may differ in size by one row; they are padded to the largest for the
+    collective and trimmed after it.
+    """
+    (row_d, row_i), (col_d, col_i) = mutual_topk_reference_sharded(queries, local_refs, k, ref_offset, group, search_fn,
+                                                                   merge_fn)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        sizes = [batch_bounds(num_refs_total, world, r) for r in range(world)]
+        widest = max(e - b for b, e in sizes)
+        pad = widest - col_d.shape[0]
+        if pad:
+            col_d = torch.cat([col_d, col_d.new_full((pad, k), float("inf"))], 0)
+            col_i = torch.cat([col_i, col_i.new_full((pad, k), -1)], 0)
+        all_d = col_d.new_empty((world * widest, k))
+        all_i = col_i.new_empty((world * widest, k))
+        dist.all_gather_into_tensor(all_d, col_d.contiguous(), group=group)
+        dist.all_gather_into_tensor(all_i, col_i.contiguous(), group=group)
+        keep = torch.cat([torch.arange(r * widest, r * widest + (e - b)) for r, (b, e) in enumerate(sizes)])
+        keep = keep.to(all_d.device)
+        col_d, col_i = all_d[keep], all_i[keep]
+    return select_fn(row_i, row_d, col_i, col_d, mutual)
