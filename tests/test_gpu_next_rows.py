@@ -601,3 +601,49 @@ def test_sharded_matching_default_kernels_single_rank(ext):
         r, c, d = sharding.mutual_matching_sharded(x, y, 1, 0, 900, mutual=mutual)
         wr, wc, wd = ops.extract_correspondences_from_feats(x, y, mutual=mutual, return_feat_dist=True, normalized=False)
         assert torch.equal(r, wr) and torch.equal(c, wc) and torch.allclose(d * d, wd)
+
+
+# ------------------------------------------------------------------------------------------------------
+# edge cases and error codes of the new entry points
+# ------------------------------------------------------------------------------------------------------
+def test_next_rows_empty_inputs_and_error_codes(ext):
+    from vision3d_amd import ops
+
+    z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device=DEV)  # noqa: E731
+    # empty selections
+    r, c, s = ops.mutual_topk_select(z(5, 7), 0)
+    assert r.numel() == 0 and c.numel() == 0 and s.numel() == 0
+    assert ops.mutual_topk_select(z(5, 7), 0, reduce_result=False).sum() == 0
+    r, c, s = ops.mutual_topk_select(torch.full((4, 4), float("-inf"), device=DEV), 1, threshold=0.0)
+    assert r.numel() == 0
+    with pytest.raises(RuntimeError, match="k must be <= 64"):
+        ext.mutual_topk_select(z(1, 100, 100), 65, num_out=z(dtype=torch.long))
+    # empty tables / clouds
+    feats = torch.randn((6, 8), device=DEV)
+    assert ops.index_select(feats, z(0, 3, dtype=torch.long), 0).shape == (0, 3, 8)
+    assert ops.local_maxpool_pack_mode(feats, z(0, 3, dtype=torch.long)).shape == (0, 8)
+    none = torch.full((4, 3), 6, dtype=torch.long, device=DEV)  # every neighbour absent
+    assert torch.all(ops.local_maxpool_pack_mode(feats, none) == 0)
+    assert torch.all(ops.knn_interpolate_pack_mode(z(4, 3), z(6, 3), feats, none) == 0)
+    pooled = ops.global_avgpool_pack_mode(feats, torch.tensor([6, 0], device=DEV))
+    assert torch.allclose(pooled[0], feats.mean(0)) and torch.isnan(pooled[1]).all()  # torch.mean of an empty slice
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ext.local_maxpool_pack(torch.randn((6, 6), device=DEV), none, z(4, 6))
+    f = feats.clone().requires_grad_(True)  # backward with a table that names nobody: zero gradient
+    ops.local_maxpool_pack_mode(f, none).sum().backward()
+    assert torch.all(f.grad == 0)
+    # kpconv: no neighbours at all -> zeros and a count of 1; too many neighbours for the fused kernel -> formulation path
+    w, n = ops.kpconv_gather(z(4, 3), z(6, 3), feats, none, torch.randn((15, 3), device=DEV), 0.1)
+    assert torch.all(w == 0) and torch.all(n == 1)
+    with pytest.raises(RuntimeError, match="at most 64 neighbours"):
+        ext.kpconv_gather(z(4, 3), z(6, 3), feats, z(4, 65, dtype=torch.long), z(15, 3), z(4, 15, 8), None, 0.1)
+    wide = torch.randint(0, 6, (4, 70), device=DEV)
+    w2, _ = ops.kpconv_gather(torch.rand((4, 3), device=DEV), torch.rand((6, 3), device=DEV), feats, wide,
+                              torch.zeros((15, 3), device=DEV), 2.0)
+    assert w2.shape == (4, 15, 8) and torch.isfinite(w2).all()
+    # partition: a single node owns everything; grouping with K = 1 and an out-of-range index reading as zero
+    p2n, sizes, masks, knn, kmask = ops.point_to_node_partition(torch.rand((9, 3), device=DEV), z(1, 3), return_count=True)
+    assert torch.all(p2n == 0) and int(sizes[0]) == 9 and knn.shape == (1, 9) and bool(kmask.all())
+    idx = torch.tensor([[[0], [9]]], device=DEV)
+    out = ops.sa_group(z(1, 3, 2), torch.ones((1, 3, 4), device=DEV), None, idx)
+    assert torch.all(out[0, :, 0, 0] == 1) and torch.all(out[0, :, 1, 0] == 0)

@@ -128,3 +128,59 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
         _lib.lib()
+
+
+def test_next_row_ops_signatures_and_no_cpu_path():
+    """SURVEY 8f mirrors: same parameter names as the reference's functions, and CPU tensors are refused (no fallback)."""
+    import inspect
+
+    from vision3d_amd import ops
+
+    expect = {
+        # vision3d/ops/mutual_topk_select.py:7-14, :63-72
+        "mutual_topk_select": ["score_mat", "k", "largest", "threshold", "mutual", "reduce_result"],
+        "batch_mutual_topk_select": ["score_mat", "k", "row_masks", "col_masks", "largest", "threshold", "mutual",
+                                     "reduce_result"],
+        # ops/matching.py:11-17, :125-127
+        "extract_correspondences_from_scores": ["score_mat", "mutual", "has_dustbin", "threshold", "return_score"],
+        "extract_correspondences_from_feats": ["src_feats", "tgt_feats", "mutual", "return_feat_dist", "normalized"],
+        # ops/point_cloud_partition.py:41-48, :108-114
+        "point_to_node_partition": ["points", "nodes", "point_limit", "return_count", "gather_points", "inf"],
+        "ball_query_partition": ["points", "nodes", "radius", "point_limit", "return_count"],
+        # ops/index_select.py:4, ops/pooling.py:6,22, ops/nearest_interpolate.py:6, ops/knn_interpolate.py:43-50
+        "index_select": ["inputs", "indices", "dim"],
+        "local_maxpool_pack_mode": ["feats", "neighbor_indices"],
+        "global_avgpool_pack_mode": ["feats", "lengths"],
+        "nearest_interpolate_pack_mode": ["inputs", "neighbor_indices"],
+        "knn_interpolate_pack_mode": ["q_points", "s_points", "s_feats", "neighbor_indices", "k", "eps"],
+    }
+    for name, args in expect.items():
+        assert list(inspect.signature(getattr(ops, name)).parameters) == args, name
+    f, t = torch.zeros(5, 4), torch.zeros(3, 2, dtype=torch.long)
+    for call in (lambda: ops.mutual_topk_select(torch.zeros(4, 4), 1),
+                 lambda: ops.extract_correspondences_from_feats(f, f),
+                 lambda: ops.point_to_node_partition(torch.zeros(5, 3), torch.zeros(2, 3)),
+                 lambda: ops.local_maxpool_pack_mode(f, t),
+                 lambda: ops.global_avgpool_pack_mode(f, torch.tensor([5])),
+                 lambda: ops.nearest_interpolate_pack_mode(f, t),
+                 lambda: ops.knn_interpolate_pack_mode(torch.zeros(3, 3), torch.zeros(5, 3), f, t),
+                 lambda: ops.sa_group(torch.zeros(1, 3, 2), torch.zeros(1, 3, 5), None, torch.zeros(1, 2, 2, dtype=torch.long)),
+                 lambda: ops.edge_group(torch.zeros(1, 4, 2), torch.zeros(1, 4, 5), torch.zeros(1, 2, 2, dtype=torch.long)),
+                 lambda: ops.kpconv_gather(torch.zeros(3, 3), torch.zeros(5, 3), f, t, torch.zeros(15, 3), 0.1)):
+        with pytest.raises(RuntimeError, match="CUDA"):
+            call()
+    # the generic index_select keeps the reference's semantics on any device for layouts outside the native kernel
+    x = torch.arange(24.0).view(2, 3, 4)
+    idx = torch.tensor([[0, 2], [1, 1]])
+    out = ops.index_select(x, idx, dim=1)
+    assert out.shape == (2, 2, 2, 4) and torch.equal(out[:, 1, 0], x[:, 1])
+
+
+def test_select_shim_validates_before_touching_the_gpu():
+    with pytest.raises(RuntimeError, match="score_mat must be a CUDA tensor"):
+        ext.mutual_topk_select(torch.zeros(1, 3, 3), 1, num_out=torch.zeros((), dtype=torch.long))
+    with pytest.raises(RuntimeError, match="feats must be a CUDA tensor"):
+        ext.local_maxpool_pack(torch.zeros(3, 4), torch.zeros(2, 2, dtype=torch.long), torch.zeros(2, 4))
+    with pytest.raises(RuntimeError, match="q_points must be a CUDA tensor"):
+        ext.sa_group(torch.zeros(1, 3, 2), torch.zeros(1, 3, 4), None, torch.zeros(1, 2, 2, dtype=torch.long),
+                     torch.zeros(1, 3, 2, 2))
