@@ -273,6 +273,12 @@ int v3d_kpconv_gather_f32(const float* q_points, const float* s_points, const fl
                           const int64_t* neighbor_indices, const float* kernel_points, float* weighted_feats,
                           int64_t* neighbor_num, int64_t M, int64_t N, int H, int K, int C, float sigma, void* workspace,
                           size_t workspace_bytes, int device, void* stream);
+/* Backward of the aggregation w.r.t. s_feats, first half: grad_neighbors (M,H,C) = influences^T x grad_weighted (M,K,C),
+ * influences recomputed (the reference's autograd keeps the (M,K,H) weights and the (M,H,C) gather alive instead).  The
+ * second half is v3d_rows_scatter_f32 (mode 0) over the neighbour table's CSR: atomic-free, ordered. */
+int v3d_kpconv_gather_bwd_f32(const float* q_points, const float* s_points, const int64_t* neighbor_indices,
+                              const float* kernel_points, const float* grad_weighted, float* grad_neighbors, int64_t M,
+                              int64_t N, int H, int K, int C, float sigma, int device, void* stream);
 
 /* ---- point-to-node partition (vision3d/ops/point_cloud_partition.py:40-104) ------------------------
  * points (N,3), nodes (M,3) fp32.  v3d_point_to_node_partition_f32: point_to_node (N) = nearest node of every point

@@ -647,3 +647,17 @@ def test_next_rows_empty_inputs_and_error_codes(ext):
     idx = torch.tensor([[[0], [9]]], device=DEV)
     out = ops.sa_group(z(1, 3, 2), torch.ones((1, 3, 4), device=DEV), None, idx)
     assert torch.all(out[0, :, 0, 0] == 1) and torch.all(out[0, :, 1, 0] == 0)
+
+
+@pytest.mark.parametrize("n,m,h,k,c", [(300, 200, 38, 15, 64), (64, 40, 64, 16, 32), (400, 333, 5, 7, 4), (200, 150, 17, 15, 132)])
+def test_kpconv_gather_backward_vs_oracle(ext, oracle_mod, n, m, h, k, c):
+    rng = np.random.default_rng(n * 3 + m + h + k + c)
+    q, s, feats, table, kpts = _kpconv_case(rng, n, m, h, k, c)
+    sigma = 0.06
+    _, _, w = oracle_mod.kpconv_gather(q, s, feats, table, kpts, sigma)  # (M,K,H) influences, float32 reference order
+    gw = rng.standard_normal((m, k, c)).astype(np.float32)
+    want = np.matmul(np.transpose(w, (0, 2, 1)).astype(np.float64), gw.astype(np.float64))
+    scale = np.matmul(np.transpose(w, (0, 2, 1)).astype(np.float64), np.abs(gw).astype(np.float64))
+    got = torch.full((m, h, c), float("nan"), device=DEV)
+    ext.kpconv_gather_backward(T(q), T(s), T(table), T(kpts), T(gw), got, sigma)
+    assert np.all(np.abs(N_(got).astype(np.float64) - want) <= 1e-5 * scale + 1e-30)

@@ -213,6 +213,11 @@ def main():
         add(f"kpconv_gather N{n} H{h} C{c}",
             lambda s_pts=s_pts, feats=feats, near=near, kpts=kpts, wf=wf, num=num: ext.kpconv_gather(
                 s_pts, s_pts, feats, near, kpts, wf, num, 0.05), flops, "TFLOP/s")
+        gw = torch.randn((n, 15, c), generator=g).to(DEV)
+        gn = torch.empty((n, h, c), device=DEV)
+        add(f"kpconv_gather_bwd N{n} H{h} C{c}",
+            lambda s_pts=s_pts, near=near, kpts=kpts, gw=gw, gn=gn: ext.kpconv_gather_backward(
+                s_pts, s_pts, near, kpts, gw, gn, 0.05), flops, "TFLOP/s")
         if n <= 120000:
             def torch_form(s_pts=s_pts, feats=feats, near=near, kpts=kpts):
                 pp = torch.cat([s_pts, torch.zeros_like(s_pts[:1]) + 1e6], 0)

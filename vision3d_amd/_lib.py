@@ -83,6 +83,8 @@ SIGNATURES = {
     "v3d_point_to_node_partition_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + _WS + _TAIL),
     "v3d_point_to_node_knn": (_c_int, [_c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr] + _TAIL),
+    "v3d_kpconv_gather_bwd_f32": (
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_f32] + _TAIL),
     "v3d_rows_csr_bytes": (_c_size, [_c_i64, _c_i64]),
     "v3d_rows_csr_build": (_c_int, [_c_ptr, _c_i64, _c_i64] + _WS + _TAIL),
     "v3d_rows_scatter_f32": (

@@ -149,6 +149,92 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
   }
 }
 
+// Backward w.r.t. the features, first half: grad_neighbors[m,h,:] = sum_kp influence[m,kp,h] * grad_weighted[m,kp,:]
+// (the transpose of the forward product; the second half is the ordered row scatter of packops.hip).  Same mapping as
+// the forward with the roles swapped: MFMA rows = 16 neighbours, k = 4 kernel points per step (4 steps), columns =
+// channels; the influences are recomputed in the A-operand layout, the B operand is grad_weighted read as 16-byte
+// pieces (256 contiguous bytes per kernel point), the result leaves as 256 contiguous bytes per neighbour.
+__global__ __launch_bounds__(256) void kpconv_gather_bwd_kernel(const float* __restrict__ q_points,
+                                                                const float* __restrict__ s_points,
+                                                                const int64_t* __restrict__ idx,
+                                                                const float* __restrict__ kernel_points,
+                                                                const float4* __restrict__ grad_weighted,
+                                                                float4* __restrict__ grad_neighbors, int64_t M, int N,
+                                                                int H, int K, int C4, float sigma) {
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, grp = lane >> 4;
+  const int64_t waves = (int64_t)gridDim.x * 4;
+  const int RT = (H + 15) >> 4;
+  float kx[4], ky[4], kz[4];
+  bool kv[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int kp = 4 * st + grp;
+    kv[st] = kp < K;
+    kx[st] = kv[st] ? kernel_points[kp * 3 + 0] : 0.f;
+    ky[st] = kv[st] ? kernel_points[kp * 3 + 1] : 0.f;
+    kz[st] = kv[st] ? kernel_points[kp * 3 + 2] : 0.f;
+  }
+  const int chunks = (C4 + 15) >> 4;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += waves) {
+    int row = -1;
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    if (lane < H) {
+      const int64_t i = idx[m * H + lane];
+      if (i >= 0 && i < N) {
+        row = (int)i;
+        ox = s_points[i * 3 + 0] - q_points[m * 3 + 0];
+        oy = s_points[i * 3 + 1] - q_points[m * 3 + 1];
+        oz = s_points[i * 3 + 2] - q_points[m * 3 + 2];
+      }
+    }
+    float A[4][4];  // [row tile][step]: neighbour 16*rt + col, kernel point 4*st + grp
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int h = 16 * rt + col;
+      const float nx = __shfl(ox, h, 64), ny = __shfl(oy, h, 64), nz = __shfl(oz, h, 64);
+      const int r = __shfl(row, h, 64);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const float dx = nx - kx[st], dy = ny - ky[st], dz = nz - kz[st];
+        const float sq = (dx * dx + dy * dy) + dz * dz;
+        const float w = fmaxf(1.f - sqrtf(sq) / sigma, 0.f);
+        A[rt][st] = (rt < RT && r >= 0 && kv[st]) ? w : 0.f;
+      }
+    }
+    for (int ch = 0; ch < chunks; ++ch) {
+      const int p = ch * 16 + col;
+      const bool pin = p < C4;
+      float4 Bv[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        Bv[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pin && kv[st]) Bv[st] = grad_weighted[(m * K + 4 * st + grp) * C4 + p];
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        if (rt < RT) {
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rt][st], Bv[st].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rt][st], Bv[st].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rt][st], Bv[st].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rt][st], Bv[st].w, acc3, 0, 0, 0);
+          }
+          if (pin) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int h = 16 * rt + grp * 4 + i;
+              if (h < H) grad_neighbors[(m * H + h) * C4 + p] = make_float4(acc0[i], acc1[i], acc2[i], acc3[i]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace v3d
 
 extern "C" {
@@ -213,6 +299,35 @@ int v3d_kpconv_gather_f32(const float* q_points, const float* s_points, const fl
     }
   }
   return rc;
+}
+
+int v3d_kpconv_gather_bwd_f32(const float* q_points, const float* s_points, const int64_t* neighbor_indices,
+                              const float* kernel_points, const float* grad_weighted, float* grad_neighbors, int64_t M,
+                              int64_t N, int H, int K, int C, float sigma, int device, void* stream_) {
+  using namespace v3d;
+  const char* what = "kpconv_gather_backward";
+  V3D_REQUIRE(M >= 0 && N >= 0 && H >= 0 && K >= 0 && C >= 0, what, "negative dimension");
+  V3D_REQUIRE(H <= kKpMaxNeighbors, what, "at most 64 neighbours per query");
+  V3D_REQUIRE(K <= kKpMaxKernelPoints, what, "at most 16 kernel points");
+  V3D_REQUIRE(C % 4 == 0, what, "the channel count must be a multiple of 4 (16-byte row pieces)");
+  V3D_REQUIRE(sigma > 0.f, what, "sigma must be positive");
+  if (N >= (int64_t)INT32_MAX) {
+    set_last_error("%s: N must stay below 2^31", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  if (M == 0 || H == 0 || C == 0) return 0;
+  V3D_REQUIRE(q_points && neighbor_indices && grad_neighbors && (K == 0 || (kernel_points && grad_weighted)) &&
+                  (N == 0 || s_points),
+              what, "null pointer");
+  V3D_REQUIRE((((uintptr_t)grad_weighted | (uintptr_t)grad_neighbors) & 15) == 0, what,
+              "gradient buffers must be 16-byte aligned");
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  const int64_t blocks = std::min<int64_t>(ceil_div(M, 4), 256 * 8);
+  hipLaunchKernelGGL(kpconv_gather_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     q_points, s_points, neighbor_indices, kernel_points, reinterpret_cast<const float4*>(grad_weighted),
+                     reinterpret_cast<float4*>(grad_neighbors), M, (int)N, H, K, C / 4, sigma);
+  return launch_status(what);
 }
 
 }  // extern "C"

@@ -43,6 +43,7 @@ __all__ = [
     "sa_group",
     "edge_group",
     "kpconv_gather",
+    "kpconv_gather_backward",
     "point_to_node_partition",
     "point_to_node_knn",
 ]
@@ -667,3 +668,22 @@ def point_to_node_knn(workspace, num_points, node_knn_indices, node_knn_masks=No
     dev, stream = _where(node_knn_indices)
     _lib.check(_lib.lib().v3d_point_to_node_knn(workspace.data_ptr(), int(num_points), M, K, node_knn_indices.data_ptr(),
                                                 _ptr(node_knn_masks), dev, stream), "point_to_node_partition")
+
+
+def kpconv_gather_backward(q_points, s_points, neighbor_indices, kernel_points, grad_weighted, grad_neighbors, sigma):
+    """grad_weighted (M,K,C) -> grad_neighbors (M,H,C) = influences^T x grad_weighted (then ``rows_scatter`` mode 0)."""
+    for t, n in ((q_points, "q_points"), (s_points, "s_points"), (kernel_points, "kernel_points"),
+                 (grad_weighted, "grad_weighted"), (grad_neighbors, "grad_neighbors")):
+        _check_cuda_contiguous(t, n)
+        _check_float(t, n)
+    _check_cuda_contiguous(neighbor_indices, "neighbor_indices")
+    _check_long(neighbor_indices, "neighbor_indices")
+    M, H = neighbor_indices.shape
+    K, C = grad_weighted.shape[1], grad_weighted.shape[2]
+    if tuple(grad_neighbors.shape) != (M, H, C) or grad_weighted.shape[0] != M or kernel_points.shape[0] != K:
+        raise RuntimeError("kpconv_gather_backward: expected grad_weighted (M,K,C), grad_neighbors (M,H,C)")
+    dev, stream = _where(grad_weighted)
+    _lib.check(_lib.lib().v3d_kpconv_gather_bwd_f32(
+        q_points.data_ptr(), s_points.data_ptr(), neighbor_indices.data_ptr(), kernel_points.data_ptr(),
+        grad_weighted.data_ptr(), grad_neighbors.data_ptr(), M, s_points.shape[0], H, K, C, float(sigma), dev, stream),
+        "kpconv_gather_backward")

@@ -4,8 +4,9 @@
 adds the layer's remaining arithmetic (the einsum with the convolution weights -- a plain GEMM, left to the BLAS --, the
 density normalisation and the bias), so a KPConv layer can call it with its own parameters.  Forward: one fused kernel
 (``ext.kpconv_gather``: fp32-input MFMA, the gathered (M,H,C) tensor and the (M,H,K,3) differences never exist).
-Backward w.r.t. the features: the kernel-point influences are recomputed, ``grad_neighbor_feats = influences^T @
-grad_weighted`` and the atomic-free row scatter of ``ops.pack_gather`` sums it per source in table order.
+Backward w.r.t. the features: ``ext.kpconv_gather_backward`` recomputes the kernel-point influences and forms
+``grad_neighbor_feats = influences^T @ grad_weighted`` on the MFMA, then the atomic-free row scatter of
+``ops.pack_gather`` sums it per source in table order.
 """
 from typing import Optional
 
@@ -46,10 +47,12 @@ class _KPConvGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_weighted, _grad_num):
         q_points, s_points, kernel_points = ctx.saved_tensors
-        w = _influences(q_points, s_points, ctx.table, kernel_points, ctx.sigma)  # (M, K, H)
-        grad_neighbor = torch.matmul(w.transpose(1, 2), grad_weighted.contiguous())  # (M, H, C)
-        m, h, c = grad_neighbor.shape
-        out = grad_neighbor.new_empty((ctx.num_sources, c))
+        m, h = ctx.table.shape
+        c = grad_weighted.shape[2]
+        grad_neighbor = grad_weighted.new_empty((m, h, c))
+        ext.kpconv_gather_backward(q_points, s_points, ctx.table, kernel_points, grad_weighted.contiguous(),
+                                   grad_neighbor, ctx.sigma)
+        out = grad_weighted.new_empty((ctx.num_sources, c))
         ext.rows_scatter(grad_neighbor.view(m * h, c), table_csr(ctx.table, ctx.num_sources), out, (m * h, 1), mode=0)
         return None, None, out, None, None, None
 
