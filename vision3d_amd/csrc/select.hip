@@ -27,6 +27,7 @@
 namespace v3d {
 
 constexpr int kSelMaxK = 64;
+constexpr int kSelLargest = 1, kSelMutual = 2, kSelThreshold = 4;
 constexpr int kSelEmptyKey = INT32_MAX;  // above the image of +inf: an unfilled list slot
 
 __device__ __forceinline__ int sel_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
@@ -90,11 +91,38 @@ __global__ __launch_bounds__(256) void sel_rows_kernel(const float* __restrict__
   }
 }
 
+// Column side for small matrices (L2-resident): one wave per column, lane l reads row r0 + l of that column (stride M);
+// the tile kernel below needs M / 64 x row-range workgroups and is launch-latency bound under a few hundred columns.
+__global__ __launch_bounds__(256) void sel_cols_strided_kernel(const float* __restrict__ score, int B, int N, int M, int k,
+                                                               int largest, int* __restrict__ out_i,
+                                                               float* __restrict__ out_v) {
+  const int lane = threadIdx.x & 63;
+  const int64_t colid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (colid >= (int64_t)B * M) return;
+  const float* base = score + (colid / M) * (int64_t)N * M + (colid % M);
+  int lk = kSelEmptyKey, li = -1;
+  for (int r0 = 0; r0 < N; r0 += 256) {
+    int key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * 64 + lane;
+      key[u] = r < N ? sel_key(base[(int64_t)r * M], largest) : kSelEmptyKey;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sel_push(lk, li, key[u], r0 + u * 64 + lane, k, lane);
+  }
+  if (lane < k) {
+    out_i[colid * k + lane] = li;
+    out_v[colid * k + lane] = li >= 0 ? sel_unkey(lk, largest) : 0.f;
+  }
+}
+
 // ---- column side: workgroup = 64 columns x one row range of one matrix -----------------------------------------
 constexpr int kColTile = 64;
 __global__ __launch_bounds__(256) void sel_cols_kernel(const float* __restrict__ score, int B, int N, int M, int k,
                                                        int largest, int rows_per_split, int* __restrict__ part_k,
-                                                       int* __restrict__ part_i) {
+                                                       int* __restrict__ part_i, int* __restrict__ fin_i,
+                                                       float* __restrict__ fin_v) {
   __shared__ int tile[2][kColTile][kColTile + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c0 = blockIdx.x * kColTile, s = blockIdx.y, b = blockIdx.z;
@@ -124,8 +152,13 @@ __global__ __launch_bounds__(256) void sel_cols_kernel(const float* __restrict__
     const int c = c0 + w * 16 + j;
     if (c < M && lane < k) {
       const int64_t o = (((int64_t)s * B + b) * M + c) * k + lane;
-      part_k[o] = lk[j];
-      part_i[o] = li[j];
+      if (fin_i) {  // a single row range: these ARE the column lists
+        fin_i[o] = li[j];
+        fin_v[o] = li[j] >= 0 ? sel_unkey(lk[j], largest) : 0.f;
+      } else {
+        part_k[o] = lk[j];
+        part_i[o] = li[j];
+      }
     }
   }
 }
@@ -183,8 +216,6 @@ __global__ __launch_bounds__(256) void sel_keys_kernel(const IndexT* __restrict_
   vals[e] = (int)e;
 }
 
-constexpr int kSelLargest = 1, kSelMutual = 2, kSelThreshold = 4;
-
 __global__ __launch_bounds__(256) void sel_flags_kernel(const unsigned long long* __restrict__ keys,
                                                         const int* __restrict__ vals, const float* __restrict__ row_v,
                                                         const float* __restrict__ col_v,
@@ -234,6 +265,206 @@ __global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long*
   if (out_s) {
     const int e = vals[i];
     out_s[at] = e < nR ? row_v[e] : col_v[e - nR];
+  }
+}
+
+// ---- small problems (<= 4096 candidates: superpoint matching, a few hundred rows and columns) -------------------------
+// ONE workgroup does what the five launches below do: keys into LDS, bitonic sort of (key, entry) pairs, duplicate /
+// head flags with threshold and masks, block-wide exclusive scan, emit.  The launch count, not the work, bounds these
+// sizes (512 x 512, k = 3: 140 us through the general path, of which ~100 us are launch gaps).
+constexpr int kSelSmallMax = 4096;
+template <typename IndexT>
+__global__ __launch_bounds__(1024) void sel_small_kernel(const IndexT* __restrict__ row_i, const float* __restrict__ row_v,
+                                                         const IndexT* __restrict__ col_i, const float* __restrict__ col_v,
+                                                         const unsigned char* __restrict__ row_masks,
+                                                         const unsigned char* __restrict__ col_masks, int B, int N, int M,
+                                                         int k, int flags, float threshold,
+                                                         unsigned char* __restrict__ corr_mat, int64_t* __restrict__ out_b,
+                                                         int64_t* __restrict__ out_r, int64_t* __restrict__ out_c,
+                                                         float* __restrict__ out_s, int64_t* __restrict__ num_out,
+                                                         int64_t capacity) {
+  __shared__ unsigned long long skey[kSelSmallMax];
+  __shared__ int sval[kSelSmallMax];
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nR = B * N * k, T = nR + B * M * k;
+  const unsigned long long none = (unsigned long long)B * N * M;
+  int P = 64;
+  while (P < T) P <<= 1;
+  for (int e = tid; e < P; e += 1024) {
+    unsigned long long key = ~0ull;
+    if (e < T) {
+      long long b, r, c;
+      if (e < nR) {
+        const int slot = e / k;
+        b = slot / N;
+        r = slot % N;
+        c = (long long)row_i[e];
+      } else {
+        const int slot = (e - nR) / k;
+        b = slot / M;
+        c = slot % M;
+        r = (long long)col_i[e - nR];
+      }
+      const bool valid = r >= 0 && r < N && c >= 0 && c < M;
+      key = valid ? (unsigned long long)((b * N + r) * M + c) : none;
+    }
+    skey[e] = key;
+    sval[e] = e;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += 1024) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), hi = lo | stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = skey[lo], bb = skey[hi];
+        if ((a > bb) == up) {
+          skey[lo] = bb;
+          skey[hi] = a;
+          const int va = sval[lo];
+          sval[lo] = sval[hi];
+          sval[hi] = va;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // flags (4 consecutive candidates per thread), then an exclusive scan over the workgroup
+  int keep[4], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = tid * 4 + u;
+    bool on = false;
+    if (i < T) {
+      const unsigned long long key = skey[i];
+      on = key < none;
+      if (on) on = (flags & kSelMutual) ? (i + 1 < T && skey[i + 1] == key) : (i == 0 || skey[i - 1] != key);
+      if (on && (flags & kSelThreshold)) {
+        const int e = sval[i];
+        const float v = e < nR ? row_v[e] : col_v[e - nR];
+        on = (flags & kSelLargest) ? v > threshold : v < threshold;
+      }
+      if (on && (row_masks || col_masks)) {
+        const long long c = (long long)(key % (unsigned long long)M), br = (long long)(key / (unsigned long long)M);
+        if (row_masks) on = row_masks[br] != 0;
+        if (on && col_masks) on = col_masks[(br / N) * (long long)M + c] != 0;
+      }
+    }
+    keep[u] = on ? 1 : 0;
+    sum += keep[u];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int run = incl - sum, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) run += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (tid == 0 && num_out) *num_out = total;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (keep[u]) {
+      const int i = tid * 4 + u;
+      const unsigned long long key = skey[i];
+      if (corr_mat) corr_mat[key] = 1;
+      if (run < capacity) {
+        const long long c = (long long)(key % (unsigned long long)M), br = (long long)(key / (unsigned long long)M);
+        if (out_b) out_b[run] = br / N;
+        if (out_r) out_r[run] = br % N;
+        if (out_c) out_c[run] = c;
+        if (out_s) {
+          const int e = sval[i];
+          out_s[run] = e < nR ? row_v[e] : col_v[e - nR];
+        }
+      }
+      ++run;
+    }
+  }
+}
+
+// Mutual selection of small problems needs no sort at all: a row's candidates are its own k list entries, a candidate
+// (r, c) is kept iff r is in column c's list, and nonzero order is "rows ascending, columns ascending inside a row".
+// One workgroup: thread t owns rows 4t .. 4t+3 (keep masks of k <= 64 bits), block scan of the row counts, emit.
+template <typename IndexT>
+__global__ __launch_bounds__(1024) void sel_mutual_small_kernel(const IndexT* __restrict__ row_i,
+                                                                const float* __restrict__ row_v,
+                                                                const IndexT* __restrict__ col_i,
+                                                                const unsigned char* __restrict__ row_masks,
+                                                                const unsigned char* __restrict__ col_masks, int B, int N,
+                                                                int M, int k, int flags, float threshold,
+                                                                unsigned char* __restrict__ corr_mat,
+                                                                int64_t* __restrict__ out_b, int64_t* __restrict__ out_r,
+                                                                int64_t* __restrict__ out_c, float* __restrict__ out_s,
+                                                                int64_t* __restrict__ num_out, int64_t capacity) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rows = B * N;
+  unsigned long long keep[4];
+  int sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = tid * 4 + u;
+    keep[u] = 0ull;
+    if (row < rows) {
+      const int b = row / N, r = row - b * N;
+      const bool row_on = row_masks == nullptr || row_masks[row] != 0;
+      for (int j = 0; j < k && row_on; ++j) {
+        const long long c = (long long)row_i[(long long)row * k + j];
+        if (c < 0 || c >= M) continue;
+        const IndexT* cl = col_i + ((long long)b * M + c) * k;
+        bool on = false;
+        for (int t = 0; t < k; ++t) on = on || ((long long)cl[t] == r);
+        if (on && (flags & kSelThreshold)) {
+          const float v = row_v[(long long)row * k + j];
+          on = (flags & kSelLargest) ? v > threshold : v < threshold;
+        }
+        if (on && col_masks) on = col_masks[(long long)b * M + c] != 0;
+        if (on) keep[u] |= 1ull << j;
+      }
+      sum += __builtin_popcountll(keep[u]);
+    }
+  }
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int run = incl - sum, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) run += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (tid == 0 && num_out) *num_out = total;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = tid * 4 + u;
+    const int b = row / N, r = row - b * N;
+    for (unsigned long long m = keep[u]; m; m &= m - 1) {
+      const int j = __builtin_ctzll(m);
+      const long long c = (long long)row_i[(long long)row * k + j];
+      int rank = 0;  // kept entries of this row with a smaller column come first
+      for (unsigned long long o = keep[u]; o; o &= o - 1)
+        rank += (long long)row_i[(long long)row * k + __builtin_ctzll(o)] < c ? 1 : 0;
+      const long long at = run + rank;
+      if (corr_mat) corr_mat[((long long)row) * M + c] = 1;
+      if (at < capacity) {
+        if (out_b) out_b[at] = b;
+        if (out_r) out_r[at] = r;
+        if (out_c) out_c[at] = c;
+        if (out_s) out_s[at] = row_v[(long long)row * k + j];
+      }
+    }
+    run += __builtin_popcountll(keep[u]);
   }
 }
 
@@ -317,6 +548,25 @@ static int select_from_lists(const IndexT* row_i, const float* row_v, const Inde
   return launch_status(what);
 }
 
+template <typename IndexT>
+static int select_small(const IndexT* row_i, const float* row_v, const IndexT* col_i, const float* col_v,
+                        const unsigned char* row_masks, const unsigned char* col_masks, int B, int N, int M, int k,
+                        int flags, float threshold, const SelectOut& o, hipStream_t stream, const char* what) {
+  const bool needs_values = o.out_s != nullptr || (flags & kSelThreshold);
+  if ((flags & kSelMutual) && (int64_t)B * N <= kSelSmallMax && (row_v != nullptr || !needs_values))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sel_mutual_small_kernel<IndexT>), dim3(1), dim3(1024), 0, stream, row_i, row_v,
+                       col_i, row_masks, col_masks, B, N, M, k, flags, threshold, o.corr_mat, o.out_b, o.out_r, o.out_c,
+                       o.out_s, o.num_out, o.capacity);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sel_small_kernel<IndexT>), dim3(1), dim3(1024), 0, stream, row_i, row_v, col_i,
+                       col_v, row_masks, col_masks, B, N, M, k, flags, threshold, o.corr_mat, o.out_b, o.out_r, o.out_c,
+                       o.out_s, o.num_out, o.capacity);
+  return launch_status(what);
+}
+static inline bool select_is_small(int B, int N, int M, int k) {
+  return (int64_t)B * k * ((int64_t)N + M) <= kSelSmallMax && (int64_t)B * N * M < (1ll << 40);
+}
+
 static int select_prologue(const char* what, int B, int N, int M, int k, const SelectOut& o, hipStream_t stream,
                            bool& done) {
   done = false;
@@ -389,14 +639,25 @@ int v3d_mutual_topk_select_f32(const float* score, const uint8_t* row_masks, con
   const int64_t rows = (int64_t)B * N, cols = (int64_t)B * M;
   hipLaunchKernelGGL(sel_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, stream, score, rows, M, k, largest,
                      row_i, row_v);
-  hipLaunchKernelGGL(sel_cols_kernel, dim3(col_tiles, S, B), dim3(256), 0, stream, score, B, N, M, k, largest,
-                     rows_per_split, part_k, part_i);
-  hipLaunchKernelGGL(sel_cols_merge_kernel, dim3((unsigned)ceil_div(cols, 4)), dim3(256), 0, stream, part_k, part_i, cols,
-                     S, k, largest, col_i, col_v);
+  if ((int64_t)B * N * M <= (4ll << 20) && M <= 4096) {  // small and L2-resident: one wave per column
+    hipLaunchKernelGGL(sel_cols_strided_kernel, dim3((unsigned)ceil_div(cols, 4)), dim3(256), 0, stream, score, B, N, M, k,
+                       largest, col_i, col_v);
+  } else {
+    hipLaunchKernelGGL(sel_cols_kernel, dim3(col_tiles, S, B), dim3(256), 0, stream, score, B, N, M, k, largest,
+                       rows_per_split, part_k, part_i, S == 1 ? col_i : nullptr, S == 1 ? col_v : nullptr);
+    if (S > 1)
+      hipLaunchKernelGGL(sel_cols_merge_kernel, dim3((unsigned)ceil_div(cols, 4)), dim3(256), 0, stream, part_k, part_i,
+                         cols, S, k, largest, col_i, col_v);
+  }
   rc = launch_status(what);
-  if (rc == 0)
-    rc = select_from_lists<int>(row_i, row_v, col_i, col_v, row_masks, col_masks, B, N, M, k, flags, threshold, o, base, z,
-                                stream, what);
+  if (rc == 0) {
+    if (select_is_small(B, N, M, k))
+      rc = select_small<int>(row_i, row_v, col_i, col_v, row_masks, col_masks, B, N, M, k, flags, threshold, o, stream,
+                             what);
+    else
+      rc = select_from_lists<int>(row_i, row_v, col_i, col_v, row_masks, col_masks, B, N, M, k, flags, threshold, o, base,
+                                  z, stream, what);
+  }
   hipError_t e = hipFreeAsync(base, stream);
   if (rc == 0 && e != hipSuccess) {
     set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
@@ -428,6 +689,9 @@ int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, co
   V3D_REQUIRE(row_idx && col_idx, what, "null pointer");
   V3D_REQUIRE((row_val && col_val) || (!out_score && !(flags & kSelThreshold)), what,
               "list values are required for scores / threshold");
+  if (select_is_small(B, N, M, k))
+    return select_small<int64_t>(row_idx, row_val, col_idx, col_val, row_masks, col_masks, B, N, M, k, flags, threshold, o,
+                                 stream, what);
   SelectSizes z;
   rc = select_sizes(B, N, M, k, 0, z, stream);
   if (rc) {
