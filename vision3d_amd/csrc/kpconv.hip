@@ -23,6 +23,11 @@ namespace v3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Results are written once and read by a later kernel: streaming stores keep them from displacing the gathered rows.
+__device__ __forceinline__ void kp_store(float4* dst, float a, float b, float c, float d) {
+  __builtin_nontemporal_store(f32x4{a, b, c, d}, reinterpret_cast<f32x4*>(dst));
+}
+
 constexpr int kKpMaxNeighbors = 64;
 constexpr int kKpMaxKernelPoints = 16;
 
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int kp = grp * 4 + i;  // C/D layout: row = 4*(lane>>4) + register, column = lane & 15
-          if (kp < K) out[(m * K + kp) * C4 + p] = make_float4(acc0[i], acc1[i], acc2[i], acc3[i]);
+          if (kp < K) kp_store(&out[(m * K + kp) * C4 + p], acc0[i], acc1[i], acc2[i], acc3[i]);
         }
       }
     }
@@ -176,30 +181,58 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_kernel(const float* __r
     kz[st] = kv[st] ? kernel_points[kp * 3 + 2] : 0.f;
   }
   const int chunks = (C4 + 15) >> 4;
-  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += waves) {
-    int row = -1;
-    float ox = 0.f, oy = 0.f, oz = 0.f;
-    if (lane < H) {
-      const int64_t i = idx[m * H + lane];
-      if (i >= 0 && i < N) {
-        row = (int)i;
-        ox = s_points[i * 3 + 0] - q_points[m * 3 + 0];
-        oy = s_points[i * 3 + 1] - q_points[m * 3 + 1];
-        oz = s_points[i * 3 + 2] - q_points[m * 3 + 2];
-      }
+  const int64_t m0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // software pipeline over the wave's queries: neighbour indices two strides ahead, point gather one stride ahead,
+  // and the grad_weighted pieces of the next (query, channel chunk) item requested before this item's MFMAs
+  auto load_index = [&](int64_t m) -> int {
+    if (m >= M || lane >= H) return -1;
+    const int64_t i = idx[m * H + lane];
+    return (i >= 0 && i < N) ? (int)i : -1;
+  };
+  int row = load_index(m0);
+  int row_next = load_index(m0 + waves);
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  auto load_point = [&](int r) {
+    sx = sy = sz = 0.f;
+    if (r >= 0) {
+      sx = s_points[(int64_t)r * 3 + 0];
+      sy = s_points[(int64_t)r * 3 + 1];
+      sz = s_points[(int64_t)r * 3 + 2];
     }
+  };
+  load_point(row);
+  float4 Bn[4];
+  auto load_grad = [&](int64_t m, int ch) {
+    const int p = ch * 16 + col;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      Bn[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M && p < C4 && kv[st]) Bn[st] = grad_weighted[(m * K + 4 * st + grp) * C4 + p];
+    }
+  };
+  load_grad(m0, 0);
+  for (int64_t m = m0; m < M; m += waves) {
+    const int cur_row = row;
+    const float ox = sx - q_points[m * 3 + 0], oy = sy - q_points[m * 3 + 1], oz = sz - q_points[m * 3 + 2];
+    row = row_next;
+    row_next = load_index(m + 2 * waves);
+    load_point(row);
     float A[4][4];  // [row tile][step]: neighbour 16*rt + col, kernel point 4*st + grp
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const int h = 16 * rt + col;
-      const float nx = __shfl(ox, h, 64), ny = __shfl(oy, h, 64), nz = __shfl(oz, h, 64);
-      const int r = __shfl(row, h, 64);
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const float dx = nx - kx[st], dy = ny - ky[st], dz = nz - kz[st];
-        const float sq = (dx * dx + dy * dy) + dz * dz;
-        const float w = fmaxf(1.f - sqrtf(sq) / sigma, 0.f);
-        A[rt][st] = (rt < RT && r >= 0 && kv[st]) ? w : 0.f;
+      for (int st = 0; st < 4; ++st) A[rt][st] = 0.f;
+      if (rt < RT) {  // wave-uniform: row tiles past the table width cost nothing
+        const int h = 16 * rt + col;
+        const float nx = __shfl(ox, h, 64), ny = __shfl(oy, h, 64), nz = __shfl(oz, h, 64);
+        const int r = __shfl(cur_row, h, 64);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const float dx = nx - kx[st], dy = ny - ky[st], dz = nz - kz[st];
+          const float sq = (dx * dx + dy * dy) + dz * dz;
+          const float w = fmaxf(1.f - sqrtf(sq) / sigma, 0.f);
+          A[rt][st] = (r >= 0 && kv[st]) ? w : 0.f;
+        }
       }
     }
     for (int ch = 0; ch < chunks; ++ch) {
@@ -207,10 +240,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_kernel(const float* __r
       const bool pin = p < C4;
       float4 Bv[4];
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        Bv[st] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pin && kv[st]) Bv[st] = grad_weighted[(m * K + 4 * st + grp) * C4 + p];
-      }
+      for (int st = 0; st < 4; ++st) Bv[st] = Bn[st];
+      if (ch + 1 < chunks) load_grad(m, ch + 1); else load_grad(m + waves, 0);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         if (rt < RT) {
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int h = 16 * rt + grp * 4 + i;
-              if (h < H) grad_neighbors[(m * H + h) * C4 + p] = make_float4(acc0[i], acc1[i], acc2[i], acc3[i]);
+              if (h < H) kp_store(&grad_neighbors[(m * H + h) * C4 + p], acc0[i], acc1[i], acc2[i], acc3[i]);
             }
           }
         }
