@@ -231,3 +231,39 @@ def point_to_node_partition(points, nodes, point_limit=None):
     own = np.take_along_axis(matching, order, axis=1)                               # :97-99
     knn = np.where(own, order, n).astype(np.int64)                                  # :100
     return point_to_node, node_sizes, node_masks, knn, own
+
+
+# ---- the reference extension's CPU node sampling (csrc/cpu/node_sampling/node_sampling.cpp:10-77) --------------
+def sample_nodes_with_fps(points, min_distance, num_samples):
+    """Line-by-line restatement incl. the swap-and-pop traversal (float32 sqrt distances, strict '>' / '<')."""
+    pts = np.asarray(points, dtype=np.float32)
+    n = pts.shape[0]
+    selected = []
+    unselected = list(range(n))
+    num_unselected = n
+    distances = np.full(n, np.float32(np.inf), dtype=np.float32)  # 1e40 overflows float to +inf (:33-35)
+    best_index = 0
+    while True:
+        cur = unselected[best_index]
+        selected.append(cur)
+        unselected[best_index], unselected[num_unselected - 1] = unselected[num_unselected - 1], unselected[best_index]
+        num_unselected -= 1                                                                   # :5-8, :43
+        if num_samples > 0 and len(selected) >= num_samples:
+            break                                                                             # :45
+        best_index, best_distance, index = -1, np.float32(0), 0
+        while index < num_unselected:
+            pi = unselected[index]
+            d = pts[cur] - pts[pi]
+            dist = np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], dtype=np.float32)        # :52
+            dist = min(distances[pi], dist)
+            distances[pi] = dist
+            if dist > best_distance:
+                best_index, best_distance = index, dist                                       # :56-59
+            if dist < np.float32(min_distance):
+                unselected[index], unselected[num_unselected - 1] = unselected[num_unselected - 1], unselected[index]
+                num_unselected -= 1                                                           # :61-62
+            else:
+                index += 1
+        if best_distance < np.float32(min_distance) or best_index < 0:
+            break                                                                             # :68
+    return np.asarray(selected, dtype=np.int64)

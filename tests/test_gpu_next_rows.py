@@ -661,3 +661,33 @@ def test_kpconv_gather_backward_vs_oracle(ext, oracle_mod, n, m, h, k, c):
     got = torch.full((m, h, c), float("nan"), device=DEV)
     ext.kpconv_gather_backward(T(q), T(s), T(table), T(kpts), T(gw), got, sigma)
     assert np.all(np.abs(N_(got).astype(np.float64) - want) <= 1e-5 * scale + 1e-30)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the extension's NumPy entry points used by vision3d.array_ops (csrc/pybind.cpp:34-70)
+# ------------------------------------------------------------------------------------------------------
+def test_ext_numpy_entry_points(ext, oracle_mod):
+    rng = np.random.default_rng(41)
+    lengths = np.asarray([700, 0, 900], dtype=np.int64)
+    pts = (rng.random((1600, 3), dtype=np.float32) * np.asarray([2.0, 2.0, 1.0], dtype=np.float32))
+    # radius_neighbors: all neighbours within the radius, ascending, padded with total_s, width = largest count
+    got = ext.radius_neighbors(pts, pts, lengths, lengths, 0.15)
+    full = oracle_mod.radius_search_pack(pts, pts, lengths, lengths, 0.15, 128)
+    width = int((full != 1600).sum(axis=1).max())
+    assert isinstance(got, np.ndarray) and got.dtype == np.int64 and got.shape == (1600, width)
+    assert np.array_equal(got, full[:, :width])
+    with pytest.raises(RuntimeError, match="128 or more"):
+        ext.radius_neighbors(pts, pts, lengths, lengths, 5.0)
+    # grid_subsampling
+    sp, sl = ext.grid_subsampling(pts, lengths, 0.1)
+    wp, wl = oracle_mod.grid_subsample_pack(pts, lengths, 0.1)
+    assert sp.dtype == np.float32 and np.array_equal(sp, wp) and np.array_equal(sl, wl)
+    # sample_nodes_with_fps against the restated CPU code (tie-free cloud): by count, by distance, by both
+    cloud = rng.random((3000, 3), dtype=np.float32)
+    for min_d, num in ((-1.0, 64), (0.12, -1), (0.05, 40), (0.3, 500), (0.02, -1)):
+        want = oracle_mod.sample_nodes_with_fps(cloud, min_d, num)
+        got = ext.sample_nodes_with_fps(cloud, min_d, num)
+        assert got.dtype == np.int64 and np.array_equal(got, want), (min_d, num, len(got), len(want))
+    # the helpers outside the path say so
+    with pytest.raises(NotImplementedError, match="outside the operator path"):
+        ext.compute_clusters(None, None)

@@ -184,3 +184,20 @@ def test_select_shim_validates_before_touching_the_gpu():
     with pytest.raises(RuntimeError, match="q_points must be a CUDA tensor"):
         ext.sa_group(torch.zeros(1, 3, 2), torch.zeros(1, 3, 4), None, torch.zeros(1, 2, 2, dtype=torch.long),
                      torch.zeros(1, 3, 2, 2))
+
+
+def test_ext_has_every_name_of_the_reference_module():
+    """csrc/pybind.cpp:20-158: every registered name exists; the deformation-graph / depth-image helpers raise."""
+    for name in ("radius_neighbors", "grid_subsampling", "sample_nodes_with_fps"):
+        assert callable(getattr(ext, name))
+    for name in ("depth_to_mesh", "erode_mesh", "sample_nodes", "compute_edges_geodesic", "compute_edges_euclidean",
+                 "compute_pixel_anchors_geodesic", "node_and_edge_clean_up", "update_pixel_anchors", "compute_clusters",
+                 "build_deformation_graph_from_point_cloud"):
+        with pytest.raises(NotImplementedError, match="outside the operator path"):
+            getattr(ext, name)()
+    import inspect
+
+    assert list(inspect.signature(ext.radius_neighbors).parameters) == ["q_points", "s_points", "q_lengths", "s_lenghts",
+                                                                        "radius"]
+    assert list(inspect.signature(ext.grid_subsampling).parameters) == ["points", "lengths", "voxel_size"]
+    assert list(inspect.signature(ext.sample_nodes_with_fps).parameters) == ["points", "min_distance", "num_samples"]

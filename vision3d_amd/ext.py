@@ -46,6 +46,9 @@ __all__ = [
     "kpconv_gather_backward",
     "point_to_node_partition",
     "point_to_node_knn",
+    "radius_neighbors",
+    "grid_subsampling",
+    "sample_nodes_with_fps",
 ]
 
 _FLOATING = {torch.float32: "f32", torch.float64: "f64"}
@@ -687,3 +690,102 @@ def kpconv_gather_backward(q_points, s_points, neighbor_indices, kernel_points, 
         q_points.data_ptr(), s_points.data_ptr(), neighbor_indices.data_ptr(), kernel_points.data_ptr(),
         grad_weighted.data_ptr(), grad_neighbors.data_ptr(), M, s_points.shape[0], H, K, C, float(sigma), dev, stream),
         "kpconv_gather_backward")
+
+
+# --------------------------------------------------------------------------------------------------------
+# The reference extension's NumPy (CPU) entry points that the pack-mode pyramid uses (csrc/pybind.cpp:34-70), so that
+# `vision3d.array_ops` (collate-time neighbourhood construction) finds them on `vision3d.ext`: NumPy arrays in and out
+# like the reference, the work done by the pack-mode GPU kernels above.  Differences from the CPU code are stated per
+# function.  The deformation-graph / depth-image helpers (csrc/pybind.cpp:20-32, :52-61) are outside this path.
+# --------------------------------------------------------------------------------------------------------
+def _np_to_dev(a, dtype):
+    import numpy as np
+
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dtype)).cuda()
+
+
+def radius_neighbors(q_points, s_points, q_lengths, s_lenghts, radius):
+    """(total_q, max_count) int64 neighbour table, ascending by distance, padded with total_s
+    (csrc/cpu/radius_neighbors/radius_neighbors.cpp:5-93; keyword `s_lenghts` as registered, pybind.cpp:41).
+
+    Differences: points AT the radius are included (the GPU path follows ops/radius_search.py:66, the CPU code's nanoflann
+    search is strict), and a query with more than 128 neighbours raises instead of widening the table."""
+    import numpy as np
+
+    q, s = _np_to_dev(q_points, np.float32), _np_to_dev(s_points, np.float32)
+    ql, sl = _np_to_dev(q_lengths, np.int64), _np_to_dev(s_lenghts, np.int64)
+    limit = 128
+    out = torch.empty((q.shape[0], limit), dtype=torch.long, device=q.device)
+    radius_search_pack(q, s, ql, sl, out, float(radius), limit)
+    counts = (out != s.shape[0]).sum(dim=1)
+    widest = int(counts.max().item()) if q.shape[0] else 0
+    if widest >= limit:
+        raise RuntimeError("radius_neighbors: a query has 128 or more neighbours; use radius_search_pack_mode with a limit")
+    return out[:, :widest].cpu().numpy()
+
+
+def grid_subsampling(points, lengths, voxel_size):
+    """(sampled_points (M,3) float32, sampled_lengths (B,) int64) -- csrc/cpu/grid_subsampling/grid_subsampling.cpp:30-55.
+    Voxel barycentres per cloud; rows come out ordered by (cloud, vx, vy, vz) where the CPU code emits its hash map's
+    iteration order (unspecified): compare as sets."""
+    import numpy as np
+
+    p, ln = _np_to_dev(points, np.float32), _np_to_dev(lengths, np.int64)
+    out = torch.empty_like(p)
+    out_len = torch.empty_like(ln)
+    num = torch.zeros((), dtype=torch.long, device=p.device)
+    grid_subsample_pack(p, ln, out, out_len, num, float(voxel_size))
+    m = int(num.item())
+    if m < 0:
+        raise RuntimeError("grid_subsampling: a cloud spans more than 2^18 voxels along an axis (or holds NaN)")
+    return out[:m].cpu().numpy(), out_len.cpu().numpy()
+
+
+def sample_nodes_with_fps(points, min_distance, num_samples):
+    """Indices of furthest-point samples starting at point 0, until `num_samples` are taken (if > 0) or the furthest
+    remaining point is closer than `min_distance` to the chosen set (csrc/cpu/node_sampling/node_sampling.cpp:10-77).
+
+    Runs the batch FPS kernel and cuts the sequence where the selection distance first drops below `min_distance`.
+    Among EQUALLY far candidates the kernel follows the CUDA kernel's order, the CPU code its swap-and-pop traversal: the
+    two agree on tie-free clouds."""
+    import numpy as np
+
+    p = _np_to_dev(points, np.float32)
+    n = p.shape[0]
+    if n == 0:
+        return np.zeros((0,), dtype=np.int64)
+    want = n if num_samples is None or num_samples <= 0 else min(int(num_samples), n)
+    take = want if min_distance is None or min_distance <= 0 else min(want, 1024)
+    while True:
+        dist = torch.full((1, n), 1e10, dtype=torch.float32, device=p.device)
+        idx = torch.zeros((1, take), dtype=torch.long, device=p.device)
+        furthest_point_sample(p.unsqueeze(0), dist, idx, take)
+        idx = idx[0]
+        if min_distance is None or min_distance <= 0:
+            return idx.cpu().numpy()
+        chosen = p[idx]
+        gaps = torch.cdist(chosen.double(), chosen.double())
+        gaps = gaps.masked_fill(torch.ones_like(gaps, dtype=torch.bool).triu(), float("inf")).min(dim=1)[0]
+        below = torch.nonzero(gaps.float() < float(min_distance)).view(-1)  # gaps[0] = inf: the first sample always stays
+        if below.numel():
+            return idx[: int(below[0].item())].cpu().numpy()
+        if take >= want:
+            return idx.cpu().numpy()
+        take = min(want, take * 4)
+
+
+def _outside_the_path(name):
+    def stub(*_args, **_kwargs):
+        raise NotImplementedError(
+            f"vision3d.ext.{name} belongs to the reference's deformation-graph / depth-image CPU helpers "
+            "(csrc/pybind.cpp:20-32, :52-61), which are outside the operator path this library replaces")
+
+    stub.__name__ = name
+    return stub
+
+
+for _name in ("depth_to_mesh", "erode_mesh", "sample_nodes", "compute_edges_geodesic", "compute_edges_euclidean",
+              "compute_pixel_anchors_geodesic", "node_and_edge_clean_up", "update_pixel_anchors", "compute_clusters",
+              "build_deformation_graph_from_point_cloud"):
+    globals()[_name] = _outside_the_path(_name)
+del _name
