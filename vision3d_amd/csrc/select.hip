@@ -66,24 +66,70 @@ __device__ __forceinline__ void sel_push(int& lk, int& li, const int key, const 
   }
 }
 
+// Same list, candidates in ANY index order: position and admission compare (key, index) lexicographically.
+__device__ __forceinline__ void sel_push_any(int& lk, int& li, const int key, const int idx, const int k, const int lane) {
+  int tau = __builtin_amdgcn_readlane(lk, k - 1), taui = __builtin_amdgcn_readlane(li, k - 1);
+  if (taui < 0) taui = INT32_MAX;  // an unfilled slot loses against any index
+  unsigned long long m = __ballot(key < tau || (key == tau && idx < taui));
+  while (m) {
+    const int l = __builtin_ffsll((long long)m) - 1;
+    const int ck = __builtin_amdgcn_readlane(key, l);
+    const int ci = __builtin_amdgcn_readlane(idx, l);
+    const int pos = __builtin_popcountll(__ballot(li >= 0 && (lk < ck || (lk == ck && li < ci))));
+    const int sk = sel_shr1(lk), si = sel_shr1(li);
+    if (lane > pos) {
+      lk = sk;
+      li = si;
+    } else if (lane == pos) {
+      lk = ck;
+      li = ci;
+    }
+    tau = __builtin_amdgcn_readlane(lk, k - 1);
+    taui = __builtin_amdgcn_readlane(li, k - 1);
+    if (taui < 0) taui = INT32_MAX;
+    m = __ballot(key < tau || (key == tau && idx < taui)) & ~((2ull << l) - 1ull);
+  }
+}
+
 // ---- row side: (rows, M) -> lists (rows, k) --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sel_rows_kernel(const float* __restrict__ score, int64_t rows, int M, int k,
-                                                       int largest, int* __restrict__ out_i,
+                                                       int largest, int vec4, int* __restrict__ out_i,
                                                        float* __restrict__ out_v) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* srow = score + row * M;
   int lk = kSelEmptyKey, li = -1;
-  for (int c0 = 0; c0 < M; c0 += 256) {
-    int key[4];
+  if (vec4) {
+    // 16 bytes per lane, two loads in flight: 2 KiB of the row per step.  Lane l holds columns c0 + 4l .. 4l+3, so the
+    // four pushes of a load are not in index order: the order-free push keeps ties by index.
+    for (int c0 = 0; c0 < M; c0 += 512) {
+      float4 v[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + u * 64 + lane;
-      key[u] = c < M ? sel_key(srow[c], largest) : kSelEmptyKey;
+      for (int u = 0; u < 2; ++u) {
+        const int c = c0 + u * 256 + lane * 4;
+        v[u] = c < M ? *reinterpret_cast<const float4*>(srow + c) : make_float4(0.f, 0.f, 0.f, 0.f);  // M % 4 == 0
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = c0 + u * 256 + lane * 4;
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          sel_push_any(lk, li, c < M ? sel_key(e[q], largest) : kSelEmptyKey, c + q, k, lane);
+      }
     }
+  } else {
+    for (int c0 = 0; c0 < M; c0 += 256) {
+      int key[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sel_push(lk, li, key[u], c0 + u * 64 + lane, k, lane);
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 64 + lane;
+        key[u] = c < M ? sel_key(srow[c], largest) : kSelEmptyKey;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sel_push(lk, li, key[u], c0 + u * 64 + lane, k, lane);
+    }
   }
   if (lane < k) {
     out_i[row * k + lane] = li;
@@ -120,9 +166,9 @@ __global__ __launch_bounds__(256) void sel_cols_strided_kernel(const float* __re
 // ---- column side: workgroup = 64 columns x one row range of one matrix -----------------------------------------
 constexpr int kColTile = 64;
 __global__ __launch_bounds__(256) void sel_cols_kernel(const float* __restrict__ score, int B, int N, int M, int k,
-                                                       int largest, int rows_per_split, int* __restrict__ part_k,
-                                                       int* __restrict__ part_i, int* __restrict__ fin_i,
-                                                       float* __restrict__ fin_v) {
+                                                       int largest, int rows_per_split, int vec4,
+                                                       int* __restrict__ part_k, int* __restrict__ part_i,
+                                                       int* __restrict__ fin_i, float* __restrict__ fin_v) {
   __shared__ int tile[2][kColTile][kColTile + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c0 = blockIdx.x * kColTile, s = blockIdx.y, b = blockIdx.z;
@@ -137,11 +183,30 @@ __global__ __launch_bounds__(256) void sel_cols_kernel(const float* __restrict__
   const int col = c0 + lane;
   int buf = 0;
   for (int rt = r_begin; rt < r_end; rt += kColTile, buf ^= 1) {
+    if (vec4) {  // 16 bytes per lane: one instruction brings 4 rows x 256 B (M % 4 == 0, 16-byte aligned rows)
+      float4 v[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = rt + w * 16 + i;
-      const bool in = r < r_end && col < M;
-      tile[buf][w * 16 + i][lane] = in ? sel_key(mat[(int64_t)r * M + col], largest) : kSelEmptyKey;
+      for (int i = 0; i < 4; ++i) {
+        const int r = rt + w * 16 + i * 4 + (lane >> 4), c = c0 + (lane & 15) * 4;
+        v[i] = (r < r_end && c < M) ? *reinterpret_cast<const float4*>(mat + (int64_t)r * M + c)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = w * 16 + i * 4 + (lane >> 4), cl = (lane & 15) * 4;
+        const bool in = rt + rl < r_end && c0 + cl < M;
+        tile[buf][rl][cl + 0] = in ? sel_key(v[i].x, largest) : kSelEmptyKey;
+        tile[buf][rl][cl + 1] = in ? sel_key(v[i].y, largest) : kSelEmptyKey;
+        tile[buf][rl][cl + 2] = in ? sel_key(v[i].z, largest) : kSelEmptyKey;
+        tile[buf][rl][cl + 3] = in ? sel_key(v[i].w, largest) : kSelEmptyKey;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = rt + w * 16 + i;
+        const bool in = r < r_end && col < M;
+        tile[buf][w * 16 + i][lane] = in ? sel_key(mat[(int64_t)r * M + col], largest) : kSelEmptyKey;
+      }
     }
     __syncthreads();  // the other buffer is free again once every wave has passed this barrier of the NEXT tile
 #pragma unroll
@@ -637,14 +702,16 @@ int v3d_mutual_topk_select_f32(const float* score, const uint8_t* row_masks, con
   int* part_i = reinterpret_cast<int*>(base + o_pi);
   const int largest = flags & kSelLargest;
   const int64_t rows = (int64_t)B * N, cols = (int64_t)B * M;
+  const int vec4 = (M % 4 == 0 && ((uintptr_t)score & 15) == 0 && M >= 1024) ? 1 : 0;
   hipLaunchKernelGGL(sel_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, stream, score, rows, M, k, largest,
-                     row_i, row_v);
+                     vec4, row_i, row_v);
   if ((int64_t)B * N * M <= (4ll << 20) && M <= 4096) {  // small and L2-resident: one wave per column
     hipLaunchKernelGGL(sel_cols_strided_kernel, dim3((unsigned)ceil_div(cols, 4)), dim3(256), 0, stream, score, B, N, M, k,
                        largest, col_i, col_v);
   } else {
+    const int cvec4 = (M % 4 == 0 && ((uintptr_t)score & 15) == 0) ? 1 : 0;
     hipLaunchKernelGGL(sel_cols_kernel, dim3(col_tiles, S, B), dim3(256), 0, stream, score, B, N, M, k, largest,
-                       rows_per_split, part_k, part_i, S == 1 ? col_i : nullptr, S == 1 ? col_v : nullptr);
+                       rows_per_split, cvec4, part_k, part_i, S == 1 ? col_i : nullptr, S == 1 ? col_v : nullptr);
     if (S > 1)
       hipLaunchKernelGGL(sel_cols_merge_kernel, dim3((unsigned)ceil_div(cols, 4)), dim3(256), 0, stream, part_k, part_i,
                          cols, S, k, largest, col_i, col_v);
