@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the SURVEY 8f entry points against the NumPy oracle (shapes drawn at random, small
+enough for the oracle).  A hardening aid, run by hand on the GPU box: python tools/fuzz_next_rows.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402
+from vision3d_amd import ext, ops  # noqa: E402
+
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+N_ = lambda t: t.detach().cpu().numpy()  # noqa: E731
+
+
+def table(rng, m, k, n):
+    t = rng.integers(0, max(n, 1), size=(m, k)).astype(np.int64)
+    t[rng.random((m, k)) < rng.random() * 0.5] = n
+    return t
+
+
+def one_case(rng, i):
+    kind = i % 6
+    if kind == 0:  # selection on a matrix
+        b, n, m = int(rng.integers(1, 4)), int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        k = int(rng.integers(1, min(n, m, 64) + 1))
+        score = np.round(rng.standard_normal((b, n, m)) * rng.choice([1, 4, 50])).astype(np.float32) / 4
+        largest, mutual = bool(rng.integers(2)), bool(rng.integers(2))
+        thr = None if rng.integers(2) else float(rng.standard_normal())
+        rm = rng.random((b, n)) > 0.3 if rng.integers(2) else None
+        cm = rng.random((b, m)) > 0.3 if rng.integers(2) else None
+        want = oracle.mutual_topk_select(score, k, row_masks=rm, col_masks=cm, largest=largest, threshold=thr, mutual=mutual)
+        got = ops.batch_mutual_topk_select(T(score), k, row_masks=None if rm is None else T(rm),
+                                           col_masks=None if cm is None else T(cm), largest=largest, threshold=thr,
+                                           mutual=mutual)
+        ok = all(np.array_equal(N_(g), w) for g, w in zip(got, want))
+        return ok, f"select b{b} n{n} m{m} k{k} l{largest} mu{mutual} thr{thr}"
+    if kind == 1:  # pack gathers
+        n, m, k, c = int(rng.integers(1, 600)), int(rng.integers(1, 600)), int(rng.integers(1, 70)), 4 * int(rng.integers(1, 70))
+        feats = rng.standard_normal((n, c)).astype(np.float32)
+        tb = table(rng, m, k, n)
+        out = torch.empty((m, k, c), device=DEV)
+        ext.index_select_rows(T(feats), T(tb), out)
+        ok = np.array_equal(N_(out), oracle.index_select_rows(feats, tb))
+        pooled = torch.empty((m, c), device=DEV)
+        argk = torch.empty((m, c), dtype=torch.uint8, device=DEV)
+        ext.local_maxpool_pack(T(feats), T(tb), pooled, argk)
+        wp, wa = oracle.local_maxpool_pack(feats, tb)
+        ok = ok and np.array_equal(N_(pooled), wp) and np.array_equal(N_(argk), wa)
+        csr = ext.rows_csr_build(T(tb), n)
+        up = rng.standard_normal((m, c)).astype(np.float32)
+        gs = torch.empty((n, c), device=DEV)
+        ext.rows_scatter(T(up), csr, gs, (m, k), mode=2, argk=argk)
+        ok = ok and np.array_equal(N_(gs), oracle.rows_scatter(up, tb, n, mode=2, argk=wa))
+        return ok, f"pack n{n} m{m} k{k} c{c}"
+    if kind == 2:  # fused grouping
+        b, c, n, m, k = (int(rng.integers(1, 5)), int(rng.integers(0, 40)), 4 * int(rng.integers(1, 700)),
+                         int(rng.integers(1, 300)), int(rng.integers(1, 40)))
+        sp = rng.random((b, 3, n), dtype=np.float32)
+        qp = rng.random((b, 3, m), dtype=np.float32)
+        idx = rng.integers(0, n, size=(b, m, k)).astype(np.int64)
+        sf = rng.standard_normal((b, c, n)).astype(np.float32) if c else None
+        out = torch.empty((b, c + 3, m, k), device=DEV)
+        ext.sa_group(T(qp), T(sp), T(sf) if c else None, T(idx), out)
+        ok = np.array_equal(N_(out), oracle.sa_group(qp, sp, sf, idx))
+        if c:
+            qf = rng.standard_normal((b, c, m)).astype(np.float32)
+            out = torch.empty((b, 2 * c, m, k), device=DEV)
+            ext.edge_group(T(qf), T(sf), T(idx), out)
+            ok = ok and np.array_equal(N_(out), oracle.edge_group(qf, sf, idx))
+            g = torch.empty((b, c, m, k), device=DEV)
+            ext.group_gather_forward(T(sf), T(idx), g)
+            ok = ok and np.array_equal(N_(g), oracle.group_gather_forward(sf, idx))
+        return ok, f"group b{b} c{c} n{n} m{m} k{k}"
+    if kind == 3:  # kpconv forward / backward
+        n, m, h, k, c = (int(rng.integers(1, 300)), int(rng.integers(1, 300)), int(rng.integers(0, 65)),
+                         int(rng.integers(1, 17)), 4 * int(rng.integers(1, 40)))
+        s = rng.random((n, 3), dtype=np.float32) * 0.3
+        q = rng.random((m, 3), dtype=np.float32) * 0.3
+        feats = rng.standard_normal((n, c)).astype(np.float32)
+        tb = table(rng, m, h, n)
+        kpts = (rng.standard_normal((k, 3)) * 0.05).astype(np.float32)
+        sigma = 0.1
+        want, wnum, w = oracle.kpconv_gather(q, s, feats, tb, kpts, sigma)
+        out = torch.empty((m, k, c), device=DEV)
+        num = torch.empty((m,), dtype=torch.long, device=DEV)
+        ext.kpconv_gather(T(q), T(s), T(feats), T(tb), T(kpts), out, num, sigma)
+        scale = np.matmul(w.astype(np.float64), np.abs(oracle.index_select_rows(feats, tb)).astype(np.float64))
+        ok = np.array_equal(N_(num), wnum) and np.all(np.abs(N_(out) - want) <= 1e-5 * scale + 1e-30)
+        if h:
+            gw = rng.standard_normal((m, k, c)).astype(np.float32)
+            gn = torch.empty((m, h, c), device=DEV)
+            ext.kpconv_gather_backward(T(q), T(s), T(tb), T(kpts), T(gw), gn, sigma)
+            wt = np.transpose(w, (0, 2, 1)).astype(np.float64)
+            ok = ok and np.all(np.abs(N_(gn) - np.matmul(wt, gw.astype(np.float64)))
+                               <= 1e-5 * np.matmul(wt, np.abs(gw).astype(np.float64)) + 1e-30)
+        return ok, f"kpconv n{n} m{m} h{h} k{k} c{c}"
+    if kind == 4:  # partition
+        n, m = int(rng.integers(1, 1500)), int(rng.integers(1, 200))
+        pts = rng.random((n, 3), dtype=np.float32)
+        nodes = rng.random((m, 3), dtype=np.float32)
+        lim = None if rng.integers(2) else int(rng.integers(1, 64))
+        want = oracle.point_to_node_partition(pts, nodes, lim)
+        got = ops.point_to_node_partition(T(pts), T(nodes), point_limit=lim, return_count=True)
+        ok = all(np.array_equal(N_(g), w) for g, w in zip(got, want))
+        return ok, f"partition n{n} m{m} lim{lim}"
+    # lists back end with a batch
+    b, n, m, k = int(rng.integers(1, 4)), int(rng.integers(1, 200)), int(rng.integers(1, 200)), int(rng.integers(1, 6))
+    k = min(k, n, m)
+    score = rng.standard_normal((b, n, m)).astype(np.float32)
+    ri = np.argsort(score, axis=2, kind="stable")[:, :, :k]
+    ci = np.transpose(np.argsort(score, axis=1, kind="stable")[:, :k, :], (0, 2, 1))
+    rv = np.take_along_axis(score, ri, axis=2)
+    cv = np.take_along_axis(np.transpose(score, (0, 2, 1)), ci, axis=2)
+    mutual = bool(rng.integers(2))
+    want = oracle.mutual_topk_select(score, k, largest=False, mutual=mutual)
+    bound = b * k * (n + m)
+    idx = torch.empty((3, bound), dtype=torch.long, device=DEV)
+    sc = torch.empty((bound,), device=DEV)
+    cnt = torch.zeros((), dtype=torch.long, device=DEV)
+    ext.mutual_select_lists(T(ri.astype(np.int64)), T(rv), T(ci.astype(np.int64)), T(cv), m, out_batch=idx[0],
+                            out_row=idx[1], out_col=idx[2], out_score=sc, num_out=cnt, largest=False, mutual=mutual)
+    c_ = int(cnt.item())
+    ok = c_ == len(want[0]) and all(np.array_equal(N_(idx[j, :c_]), want[j]) for j in range(3)) and \
+        np.array_equal(N_(sc[:c_]), want[3])
+    return ok, f"lists b{b} n{n} m{m} k{k} mu{mutual}"
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for i in range(cases):
+        ok, what = one_case(rng, i)
+        if not ok:
+            bad += 1
+            print("MISMATCH", what, flush=True)
+        if i % 50 == 49:
+            print(f"{i + 1} cases, {bad} mismatches", flush=True)
+    torch.cuda.synchronize()
+    print(f"done: {cases} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
