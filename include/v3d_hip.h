@@ -207,6 +207,27 @@ int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, co
                                 int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
                                 int device, void* stream);
 
+/* The two other selectors of vision3d/ops/matching.py, on a 2-D score matrix (N,M) fp32.
+ * v3d_threshold_select_f32 replaces extract_correspondences_from_scores_threshold (:64-86) after its torch.exp: the cells
+ * with score > threshold (V3D_SEL_LARGEST; < threshold without it) in torch.nonzero order -> out_row / out_col int64,
+ * out_score fp32 (each may be NULL), at most `capacity` entries written, the true count in *num_out (device scalar,
+ * required).  The matrix is read twice (count, emit); up to 64 Ki cells it is one launch.
+ * v3d_global_topk_select_f32 replaces extract_correspondences_from_scores_topk (:89-121) and the flat top-k of
+ * SuperPointMatchingGlobalTopk (models/geotransformer/superpoint_matching_global_topk.py:61-64): the k best cells of the
+ * flattened matrix (largest with V3D_SEL_LARGEST), best first like torch.topk(sorted=True), equal scores by ascending
+ * flat index (torch leaves that open); k > N*M is torch.topk's "selected index k out of range"; with V3D_SEL_DUSTBIN the
+ * entries of the last row / last column are dropped AFTER the selection (:110-115), so *num_out <= k (it equals k
+ * without the flag; num_out may be NULL then).  Exact radix select (3 histogram passes, +3 only when the k-th value is
+ * tied), one compaction pass, sort of the k winners; N*M < 2^32.  No host synchronisation in either; scratch is
+ * stream-ordered (hipMallocAsync). */
+#define V3D_SEL_DUSTBIN 8
+int v3d_threshold_select_f32(const float* score, int64_t N, int64_t M, float threshold, int flags, int64_t* out_row,
+                             int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, int device,
+                             void* stream);
+int v3d_global_topk_select_f32(const float* score, int64_t N, int64_t M, int64_t k, int flags, int64_t* out_row,
+                               int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, int device,
+                               void* stream);
+
 /* ---- "next" rows: PACK-mode row gathers (features row-major (N,C), neighbour table (M,K) int64,
  * entries equal to N -- or anything outside [0,N) -- mean "no neighbour" and read as a row of zeros, which is what the
  * reference obtains by concatenating a zero row: cat(feats, zeros(1,C)) + index_select) ------------------------------

@@ -60,6 +60,36 @@ def extract_correspondences_from_scores(score_mat, mutual=False, has_dustbin=Fal
 
 
 # ---- rank 3: pack-mode row gathers ------------------------------------------------------------------------------
+def extract_correspondences_from_scores_threshold(score_mat, threshold):
+    """ops/matching.py:78-83: (rows, cols, exp scores) of the cells with exp(score) > threshold, nonzero order."""
+    s = np.exp(np.asarray(score_mat, dtype=np.float32))                                  # :78
+    r, c = np.nonzero(s > np.float32(threshold))                                         # :79-80
+    return r.astype(np.int64), c.astype(np.int64), s[r, c]
+
+
+def threshold_select(score_mat, threshold, largest=True):
+    """The selection behind it without the exp: cells above (below) the threshold in nonzero order."""
+    s = np.asarray(score_mat, dtype=np.float32)
+    r, c = np.nonzero(s > np.float32(threshold) if largest else s < np.float32(threshold))
+    return r.astype(np.int64), c.astype(np.int64), s[r, c]
+
+
+def extract_correspondences_from_scores_topk(score_mat, k, has_dustbin=False, largest=True):
+    """ops/matching.py:107-118: flat top-k (best first; ties: lower flat index, which torch leaves open), row = idx // M,
+    col = idx % M, dustbin entries dropped afterwards."""
+    s = np.asarray(score_mat, dtype=np.float32)
+    n, m = s.shape
+    if k > s.size:
+        raise RuntimeError("selected index k out of range")
+    flat = s.reshape(-1)
+    order = np.argsort((-flat if largest else flat) + 0.0, kind="stable")[:k]            # :107
+    r, c = order // m, order % m                                                         # :108-109
+    if has_dustbin:                                                                      # :110-115
+        keep = (r != n - 1) & (c != m - 1)
+        r, c = r[keep], c[keep]
+    return r.astype(np.int64), c.astype(np.int64), s[r, c]
+
+
 def _padded(feats):
     feats = np.asarray(feats)
     return np.concatenate([feats, np.zeros_like(feats[:1])], axis=0)  # pooling.py:16, knn_interpolate.py:65-66

@@ -151,6 +151,89 @@ def make_select_fixtures():
         torch.Tensor.cuda = orig_cuda
 
 
+def make_matching_fixtures():
+    """ops/matching.py:64-121 (threshold and global top-k selection) and the two superpoint matching heads
+    (models/geotransformer/superpoint_matching_{global,mutual}_topk.py), run on the CPU.  matching.py is loaded as a
+    submodule of an empty synthetic parent package (as in make_select_fixtures); the heads import `vision3d.ops`, which is
+    given to them as a synthetic module holding the reference's own pairwise_distance / mutual_topk_select loaded by file
+    path (the real ops/__init__.py pulls in pykeops and the unbuilt extension).  Scores are tie-free."""
+    import importlib
+    import types
+
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    parent = types.ModuleType("v3dref_ops")
+    parent.__path__ = [os.path.join(REF, "ops")]
+    sys.modules["v3dref_ops"] = parent
+    saved = {n: sys.modules.get(n) for n in ("vision3d", "vision3d.ops")}
+    try:
+        matching = importlib.import_module("v3dref_ops.matching")
+        rng = np.random.default_rng(20261113)
+        out = {}
+        logits = rng.standard_normal((45, 61)).astype(np.float32)
+        log_p = (logits - np.log(np.exp(logits).sum(axis=1, keepdims=True))).astype(np.float32)
+        out["log_p"] = log_p
+        t = torch.from_numpy(log_p)
+        for i, thr in enumerate((0.02, 0.05, 0.5)):
+            r_, c_, s_ = matching.extract_correspondences_from_scores_threshold(t, thr, return_score=True)
+            out[f"thr{i}"], out[f"thr{i}_value"] = np.stack([r_.numpy(), c_.numpy()]), np.float32(thr)
+            out[f"thr{i}_scores"] = s_.numpy()
+        for k in (1, 17, 300):
+            for largest in (True, False):
+                for dustbin in (False, True):
+                    r_, c_, s_ = matching.extract_correspondences_from_scores_topk(
+                        t, k, has_dustbin=dustbin, largest=largest, return_score=True)
+                    tag = f"topk{k}_l{int(largest)}_d{int(dustbin)}"
+                    out[tag], out[tag + "_scores"] = np.stack([r_.numpy(), c_.numpy()]), s_.numpy()
+
+        pd = load_by_path("ref_pairwise_distance", os.path.join(REF, "ops", "pairwise_distance.py"))
+        mts = load_by_path("ref_mutual_topk_select", os.path.join(REF, "ops", "mutual_topk_select.py"))
+        pkg, ops_mod = types.ModuleType("vision3d"), types.ModuleType("vision3d.ops")
+        pkg.__path__ = []
+        ops_mod.pairwise_distance, ops_mod.mutual_topk_select = pd.pairwise_distance, mts.mutual_topk_select
+        pkg.ops = ops_mod
+        sys.modules["vision3d"], sys.modules["vision3d.ops"] = pkg, ops_mod
+        geo = os.path.join(REF, "models", "geotransformer")
+        g_mod = load_by_path("ref_spm_global", os.path.join(geo, "superpoint_matching_global_topk.py"))
+        m_mod = load_by_path("ref_spm_mutual", os.path.join(geo, "superpoint_matching_mutual_topk.py"))
+        src = rng.standard_normal((70, 32)).astype(np.float32)
+        tgt = rng.standard_normal((83, 32)).astype(np.float32)
+        src /= np.linalg.norm(src, axis=1, keepdims=True)
+        tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+        smask, tmask = rng.random(70) > 0.15, rng.random(83) > 0.15
+        sw, tw = rng.random(70).astype(np.float32) + 0.5, rng.random(83).astype(np.float32) + 0.5
+        out.update(spm_src=src.astype(np.float32), spm_tgt=tgt.astype(np.float32), spm_smask=smask, spm_tmask=tmask,
+                   spm_sw=sw, spm_tw=tw)
+        ts, tt = torch.from_numpy(out["spm_src"]), torch.from_numpy(out["spm_tgt"])
+        for dual in (True, False):
+            for masked in (False, True):
+                for weighted in (False, True):
+                    head = g_mod.SuperPointMatchingGlobalTopk(48, dual_normalization=dual)
+                    a, b, c = head(ts, tt,
+                                   torch.from_numpy(smask) if masked else None, torch.from_numpy(tmask) if masked else None,
+                                   torch.from_numpy(sw) if weighted else None, torch.from_numpy(tw) if weighted else None)
+                    tag = f"spmg_d{int(dual)}_m{int(masked)}_w{int(weighted)}"
+                    out[tag], out[tag + "_scores"] = np.stack([a.numpy(), b.numpy()]), c.numpy()
+        for mutual in (True, False):
+            for masked in (False, True):
+                for thr in (None, 1.05, 0.9):
+                    head = m_mod.SuperPointMatchingMutualTopk(24, 3, threshold=thr, mutual=mutual)
+                    a, b, c = head(ts, tt, torch.from_numpy(smask) if masked else None,
+                                   torch.from_numpy(tmask) if masked else None)
+                    tag = f"spmm_m{int(mutual)}_k{int(masked)}_t{'n' if thr is None else str(thr)}"
+                    out[tag], out[tag + "_scores"] = np.stack([a.numpy(), b.numpy()]), c.numpy()
+        np.savez_compressed(os.path.join(HERE, "ref_matching.npz"), **out)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        for name in [k_ for k_ in sys.modules if k_.startswith("v3dref_ops")]:
+            del sys.modules[name]
+        for n, m in saved.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m
+
+
 def make_pack_ops_fixtures():
     """ops/index_select.py, ops/pooling.py, ops/nearest_interpolate.py (pure torch) run on the CPU.  They import each other
     relatively, so they are loaded as submodules of an empty synthetic parent package whose __path__ is the reference's ops
@@ -230,7 +313,9 @@ def make_oracle_fixtures():
 
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["reference", "select", "pack", "oracle"]
+    which = sys.argv[1:] or ["reference", "select", "matching", "pack", "oracle"]
+    if "matching" in which:
+        make_matching_fixtures()
     if "pack" in which:
         make_pack_ops_fixtures()
     if "reference" in which:

@@ -144,6 +144,9 @@ def test_next_row_ops_signatures_and_no_cpu_path():
         # ops/matching.py:11-17, :125-127
         "extract_correspondences_from_scores": ["score_mat", "mutual", "has_dustbin", "threshold", "return_score"],
         "extract_correspondences_from_feats": ["src_feats", "tgt_feats", "mutual", "return_feat_dist", "normalized"],
+        # ops/matching.py:65, :90-92
+        "extract_correspondences_from_scores_threshold": ["score_mat", "threshold", "return_score"],
+        "extract_correspondences_from_scores_topk": ["score_mat", "k", "has_dustbin", "largest", "return_score"],
         # ops/point_cloud_partition.py:41-48, :108-114
         "point_to_node_partition": ["points", "nodes", "point_limit", "return_count", "gather_points", "inf"],
         "ball_query_partition": ["points", "nodes", "radius", "point_limit", "return_count"],
@@ -159,6 +162,10 @@ def test_next_row_ops_signatures_and_no_cpu_path():
     f, t = torch.zeros(5, 4), torch.zeros(3, 2, dtype=torch.long)
     for call in (lambda: ops.mutual_topk_select(torch.zeros(4, 4), 1),
                  lambda: ops.extract_correspondences_from_feats(f, f),
+                 lambda: ops.extract_correspondences_from_scores_threshold(f, 0.1),
+                 lambda: ops.extract_correspondences_from_scores_topk(f, 3),
+                 lambda: ops.SuperPointMatchingGlobalTopk(4)(f, f),
+                 lambda: ops.SuperPointMatchingMutualTopk(4, 1)(f, f),
                  lambda: ops.point_to_node_partition(torch.zeros(5, 3), torch.zeros(2, 3)),
                  lambda: ops.local_maxpool_pack_mode(f, t),
                  lambda: ops.global_avgpool_pack_mode(f, torch.tensor([5])),

@@ -87,3 +87,28 @@ def test_extract_correspondences_from_scores_oracle_matches_reference_fixture(or
                 r, c, s = oracle_mod.extract_correspondences_from_scores(g["m_log_p"], mutual, dustbin, thr)
                 assert np.array_equal(np.stack([r, c]), g[tag]), tag
                 assert np.allclose(s, g[tag + "_scores"], rtol=1e-6), tag  # exp() of numpy vs torch: 1 ulp
+
+
+def test_threshold_and_global_topk_oracle_match_reference_fixture(oracle_mod, golden):
+    """ops/matching.py:64-121 run on the CPU -> ref_matching.npz."""
+    g = golden("ref_matching.npz")
+    for i in range(3):
+        r, c, s = oracle_mod.extract_correspondences_from_scores_threshold(g["log_p"], float(g[f"thr{i}_value"]))
+        assert np.array_equal(np.stack([r, c]), g[f"thr{i}"]), i
+        assert np.allclose(s, g[f"thr{i}_scores"], rtol=1e-6), i  # exp() of numpy vs torch: 1 ulp
+    for k in (1, 17, 300):
+        for largest in (True, False):
+            for dustbin in (False, True):
+                tag = f"topk{k}_l{int(largest)}_d{int(dustbin)}"
+                r, c, s = oracle_mod.extract_correspondences_from_scores_topk(g["log_p"], k, dustbin, largest)
+                assert np.array_equal(np.stack([r, c]), g[tag]), tag
+                assert np.array_equal(s, g[tag + "_scores"]), tag
+
+
+def test_global_topk_oracle_tie_rule_and_range(oracle_mod):
+    s = np.zeros((3, 4), dtype=np.float32)
+    s[2, 1] = 1.0
+    r, c, _ = oracle_mod.extract_correspondences_from_scores_topk(s, 4)
+    assert list(zip(r, c)) == [(2, 1), (0, 0), (0, 1), (0, 2)]  # equal scores: ascending flat index
+    with pytest.raises(RuntimeError, match="out of range"):
+        oracle_mod.extract_correspondences_from_scores_topk(s, 13)

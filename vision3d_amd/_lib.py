@@ -66,6 +66,10 @@ SIGNATURES = {
     "v3d_mutual_select_lists_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_ptr,
                  _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _TAIL),
+    "v3d_threshold_select_f32": (
+        _c_int, [_c_ptr, _c_i64, _c_i64, _c_f32, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _TAIL),
+    "v3d_global_topk_select_f32": (
+        _c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _TAIL),
     "v3d_index_select_rows": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64] + _TAIL),
     "v3d_local_maxpool_pack_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_int] + _TAIL),
     "v3d_knn_interp_weights_pack_f32": (

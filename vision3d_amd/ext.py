@@ -33,6 +33,8 @@ __all__ = [
     "grid_subsample_pack",
     "mutual_topk_select",
     "mutual_select_lists",
+    "threshold_select",
+    "global_topk_select",
     "index_select_rows",
     "local_maxpool_pack",
     "knn_interp_weights_pack",
@@ -376,7 +378,7 @@ def grid_subsample_pack(points, lengths, sampled_points, sampled_lengths, num_sa
 # --------------------------------------------------------------------------------------------------------
 # Correspondence selectors: pure torch in the reference (ops/mutual_topk_select.py).
 # --------------------------------------------------------------------------------------------------------
-SEL_LARGEST, SEL_MUTUAL, SEL_THRESHOLD = 1, 2, 4
+SEL_LARGEST, SEL_MUTUAL, SEL_THRESHOLD, SEL_DUSTBIN = 1, 2, 4, 8
 
 
 def _check_bool(t, name):
@@ -465,6 +467,46 @@ def mutual_select_lists(row_idx, row_val, col_idx, col_val, num_cols_total, corr
         _ptr(corr_mat), _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev,
         stream)
     _lib.check(rc, "mutual_select_lists")
+
+
+def _matrix_select_outputs(out_row, out_col, out_score, num_out):
+    capacity = _select_outputs("select", None, None, out_row, out_col, out_score, num_out, ())
+    return capacity
+
+
+def threshold_select(score_mat, threshold, out_row=None, out_col=None, out_score=None, num_out=None, largest=True):
+    """score_mat (N,M) fp32 -> the cells with score > threshold (< if not largest) in nonzero order + device count."""
+    _check_cuda_contiguous(score_mat, "score_mat")
+    _check_float(score_mat, "score_mat")
+    if score_mat.dim() != 2:
+        raise RuntimeError("threshold_select: score_mat must be a 2-D tensor")
+    if num_out is None:
+        raise RuntimeError("threshold_select: num_out is required")
+    capacity = _matrix_select_outputs(out_row, out_col, out_score, num_out)
+    N, M = score_mat.shape
+    dev, stream = _where(score_mat)
+    rc = _lib.lib().v3d_threshold_select_f32(
+        score_mat.data_ptr(), N, M, float(threshold), SEL_LARGEST if largest else 0, _ptr(out_row), _ptr(out_col),
+        _ptr(out_score), _ptr(num_out), capacity, dev, stream)
+    _lib.check(rc, "threshold_select")
+
+
+def global_topk_select(score_mat, k, out_row=None, out_col=None, out_score=None, num_out=None, largest=True,
+                       has_dustbin=False):
+    """score_mat (N,M) fp32 -> the k best cells of the flattened matrix, best first (ties: lower flat index)."""
+    _check_cuda_contiguous(score_mat, "score_mat")
+    _check_float(score_mat, "score_mat")
+    if score_mat.dim() != 2:
+        raise RuntimeError("global_topk_select: score_mat must be a 2-D tensor")
+    if has_dustbin and num_out is None:
+        raise RuntimeError("global_topk_select: num_out is required with has_dustbin")
+    capacity = _matrix_select_outputs(out_row, out_col, out_score, num_out)
+    N, M = score_mat.shape
+    dev, stream = _where(score_mat)
+    rc = _lib.lib().v3d_global_topk_select_f32(
+        score_mat.data_ptr(), N, M, int(k), (SEL_LARGEST if largest else 0) | (SEL_DUSTBIN if has_dustbin else 0),
+        _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev, stream)
+    _lib.check(rc, "global_topk_select")
 
 
 # --------------------------------------------------------------------------------------------------------

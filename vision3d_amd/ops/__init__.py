@@ -14,7 +14,9 @@ from .group_gather import group_gather
 from .knn import knn, knn_pack_mode
 from .knn_points import knn_points
 from .kpconv import kpconv, kpconv_gather
-from .matching import extract_correspondences_from_feats, extract_correspondences_from_scores
+from .matching import (extract_correspondences_from_feats, extract_correspondences_from_scores,
+                       extract_correspondences_from_scores_threshold, extract_correspondences_from_scores_topk)
+from .superpoint_matching import SuperPointMatchingGlobalTopk, SuperPointMatchingMutualTopk
 from .mutual_topk_select import batch_mutual_topk_select, mutual_topk_select
 from .pack_gather import (global_avgpool_pack_mode, index_select, knn_interpolate_pack_mode,
                           local_maxpool_pack_mode, nearest_interpolate_pack_mode)
@@ -30,6 +32,8 @@ __all__ = [
     "group_gather", "knn", "knn_pack_mode", "knn_points", "pairwise_distance", "radius_count_pack_mode",
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats", "extract_correspondences_from_scores",
+    "extract_correspondences_from_scores_threshold", "extract_correspondences_from_scores_topk",
+    "SuperPointMatchingGlobalTopk", "SuperPointMatchingMutualTopk",
     "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
     "knn_interpolate_pack_mode", "sa_group", "edge_group", "kpconv_gather", "kpconv", "point_to_node_partition", "ball_query_partition",
 ]

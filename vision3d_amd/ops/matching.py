@@ -1,4 +1,4 @@
-"""Correspondence extraction from descriptors -- mirrors ``vision3d/ops/matching.py:124-151``.
+"""Correspondence extraction -- mirrors ``vision3d/ops/matching.py`` (all five functions, :10-151).
 
 The reference materialises the (M, N) feature-distance matrix (``pairwise_distance``) and runs ``mutual_topk_select``
 with k = 1 on it.  Here the matrix never exists: the nearest neighbour of every source descriptor among the targets and
@@ -35,6 +35,55 @@ def extract_correspondences_from_scores(
     if return_score:
         return rows, cols, scores
     return rows, cols
+
+
+@torch.no_grad()
+def extract_correspondences_from_scores_threshold(score_mat: Tensor, threshold: float, return_score: bool = False):
+    """Threshold selection on a log-probability matrix (matching.py:64-86): the cells with ``exp(score) > threshold`` in
+    ``nonzero`` order.  One elementwise ``exp`` plus ``ext.threshold_select`` (count pass, emit pass; no boolean matrix,
+    no ``nonzero``); the one host synchronisation is reading the count, which ``torch.nonzero`` needs as well."""
+    if not score_mat.is_cuda:
+        raise RuntimeError("extract_correspondences_from_scores_threshold: CUDA tensor required (no CPU fallback)")
+    score = torch.exp(score_mat).float().contiguous()  # :78
+    dev = score.device
+    count = torch.zeros((), dtype=torch.long, device=dev)
+    cap = max(min(score.numel(), 1 << 20), 1)  # every matrix of up to 1 Mi cells is one call; beyond, re-run on overflow
+    while True:
+        idx = torch.empty((2, cap), dtype=torch.long, device=dev)
+        scores = torch.empty((cap,), device=dev) if return_score else None
+        ext.threshold_select(score, threshold, out_row=idx[0], out_col=idx[1], out_score=scores, num_out=count)
+        c = int(count.item())
+        if c <= cap:
+            break
+        cap = c
+    if return_score:
+        return idx[0, :c], idx[1, :c], scores[:c].to(score_mat.dtype)
+    return idx[0, :c], idx[1, :c]
+
+
+@torch.no_grad()
+def extract_correspondences_from_scores_topk(
+    score_mat: Tensor, k: int, has_dustbin: bool = False, largest: bool = True, return_score: bool = False
+):
+    """Global top-k selection (matching.py:89-121): the k best cells of the flattened matrix, best first, entries of the
+    dustbin row / column dropped afterwards.  ``ext.global_topk_select`` = exact radix select + sort of the k winners;
+    equal scores are taken by ascending flat index (``torch.topk`` leaves that open).  Host synchronisation only with
+    ``has_dustbin`` (the reference's boolean-mask indexing has it too)."""
+    if not score_mat.is_cuda:
+        raise RuntimeError("extract_correspondences_from_scores_topk: CUDA tensor required (no CPU fallback)")
+    score = score_mat.float().contiguous()
+    if k > score.numel():
+        raise RuntimeError("selected index k out of range")  # torch.topk's message
+    dev = score.device
+    idx = torch.empty((2, max(k, 1)), dtype=torch.long, device=dev)
+    scores = torch.empty((max(k, 1),), device=dev) if return_score else None
+    count = torch.zeros((), dtype=torch.long, device=dev) if has_dustbin else None
+    ext.global_topk_select(score, k, out_row=idx[0], out_col=idx[1], out_score=scores, num_out=count, largest=largest,
+                           has_dustbin=has_dustbin)
+    c = int(count.item()) if has_dustbin else k
+    if return_score:
+        return idx[0, :c], idx[1, :c], scores[:c].to(score_mat.dtype)
+    return idx[0, :c], idx[1, :c]
 
 
 @torch.no_grad()
