@@ -177,6 +177,16 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
 int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, float* sampled_points,
                                 int64_t* sampled_lengths, int64_t* num_sampled, int B, int64_t total, float voxel_size,
                                 int device, void* stream);
+/* v3d_voxelize_pack_f32 replaces voxelize_pack_mode (vision3d/ops/voxelize.py:6-63; its batch form `voxelize` :66-100 is
+ * pack/batch conversion around it): the same per-voxel reduction with voxel = floor(p / voxel_size) (:22, a correctly
+ * rounded fp32 division; grid subsampling multiplies by 1 / voxel_size instead), and three more outputs: voxels (M,3)
+ * int64 = the integer voxel coordinates (:43-44), voxel_feats (M,C) = the voxel means of feats (N,C) (:57-60; feats = NULL,
+ * C = 0 without features), nodes (M,3) = the voxel means of the points (:46-49), voxel_lengths (B,) (:51-54).  Output
+ * order = torch.unique of the hash = ascending (cloud, vx, vy, vz); sums run in input order (no atomics): bit-reproducible.
+ * Output buffers hold `total` rows; *num_voxels = M, or -1 as above. */
+int v3d_voxelize_pack_f32(const float* points, const int64_t* lengths, const float* feats, int C, int64_t* voxels,
+                          float* nodes, float* voxel_feats, int64_t* voxel_lengths, int64_t* num_voxels, int B,
+                          int64_t total, float voxel_size, int device, void* stream);
 
 /* ---- "next" rows: correspondence selectors downstream of pairwise_distance -----------------------
  * v3d_mutual_topk_select_f32 replaces vision3d/ops/mutual_topk_select.py:7-60 (B = 1) and :63-133 (batched):

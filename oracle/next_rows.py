@@ -297,3 +297,28 @@ def sample_nodes_with_fps(points, min_distance, num_samples):
         if best_distance < np.float32(min_distance) or best_index < 0:
             break                                                                             # :68
     return np.asarray(selected, dtype=np.int64)
+
+
+def voxelize_pack(points, lengths, voxel_size, feats=None):
+    """ops/voxelize.py:20-63: voxels = floor(points / voxel_size) (fp32 division), one output per occupied (cloud, voxel)
+    in ascending (cloud, vx, vy, vz) order = torch.unique of the hash (:37-38); means of the points (:46-49) and of the
+    optional features (:57-60), summed in input order (what a sequential scatter_add_ does); per-cloud counts (:51-54)."""
+    pts = np.asarray(points, dtype=np.float32)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    vox = np.floor(pts / np.float32(voxel_size)).astype(np.int64)                          # :22
+    cloud = np.repeat(np.arange(len(lengths)), lengths)                                    # :33-35
+    keys = np.concatenate([cloud[:, None], vox], axis=1)
+    uniq, inv, counts = np.unique(keys, axis=0, return_inverse=True, return_counts=True)   # :37-38
+    inv = inv.reshape(-1)
+    nodes = np.zeros((len(uniq), 3), dtype=np.float32)
+    np.add.at(nodes, inv, pts)                                                             # :48 (sequential, input order)
+    nodes /= counts[:, None].astype(np.float32)                                            # :49
+    v_lengths = np.bincount(uniq[:, 0], minlength=len(lengths)).astype(np.int64)           # :51-54
+    out = [uniq[:, 1:].astype(np.int64), nodes]
+    if feats is not None:
+        f = np.asarray(feats, dtype=np.float32)
+        v_feats = np.zeros((len(uniq), f.shape[1]), dtype=np.float32)
+        np.add.at(v_feats, inv, f)                                                         # :59
+        v_feats /= counts[:, None].astype(np.float32)                                      # :60
+        out.append(v_feats)
+    return tuple(out) + (v_lengths,)

@@ -234,6 +234,44 @@ def make_matching_fixtures():
                 sys.modules[n] = m
 
 
+def make_voxelize_fixtures():
+    """ops/voxelize.py (pure torch) run on the CPU as a submodule of the synthetic parent package (it imports
+    .conversion relatively); its `.cuda()` calls on freshly built tensors are the identity while it runs."""
+    import importlib
+    import types
+
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    parent = types.ModuleType("v3dref_ops")
+    parent.__path__ = [os.path.join(REF, "ops")]
+    sys.modules["v3dref_ops"] = parent
+    try:
+        vox = importlib.import_module("v3dref_ops.voxelize")
+        rng = np.random.default_rng(20261114)
+        lengths = np.asarray([900, 0, 1300, 700], dtype=np.int64)
+        pts = (rng.random((int(lengths.sum()), 3)).astype(np.float32) * np.float32([3.0, 3.0, 2.5])
+               - np.float32([1.0, 0.5, 0.0]))  # negative coordinates too
+        feats = rng.standard_normal((pts.shape[0], 8)).astype(np.float32)
+        out = {"points": pts, "lengths": lengths, "feats": feats, "voxel_size": np.float32(0.3)}
+        v, n, f, l = vox.voxelize_pack_mode(torch.from_numpy(pts), torch.from_numpy(lengths), 0.3,
+                                            feats=torch.from_numpy(feats))
+        out.update(voxels=v.numpy(), nodes=n.numpy(), v_feats=f.numpy(), v_lengths=l.numpy())
+        v2, n2, l2 = vox.voxelize_pack_mode(torch.from_numpy(pts), torch.from_numpy(lengths), 0.3)
+        assert torch.equal(v, v2) and torch.equal(n, n2) and torch.equal(l, l2)
+        bpts = rng.random((3, 400, 3)).astype(np.float32)
+        bmask = rng.random((3, 400)) > 0.3
+        bfeats = rng.standard_normal((3, 400, 4)).astype(np.float32)
+        bv, bn, bf, bm = vox.voxelize(torch.from_numpy(bpts), 0.25, masks=torch.from_numpy(bmask),
+                                      feats=torch.from_numpy(bfeats))
+        out.update(b_points=bpts, b_masks=bmask, b_feats=bfeats, b_voxels=bv.numpy(), b_nodes=bn.numpy(),
+                   b_v_feats=bf.numpy(), b_v_masks=bm.numpy())
+        np.savez_compressed(os.path.join(HERE, "ref_voxelize.npz"), **out)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        for name in [k_ for k_ in sys.modules if k_.startswith("v3dref_ops")]:
+            del sys.modules[name]
+
+
 def make_pack_ops_fixtures():
     """ops/index_select.py, ops/pooling.py, ops/nearest_interpolate.py (pure torch) run on the CPU.  They import each other
     relatively, so they are loaded as submodules of an empty synthetic parent package whose __path__ is the reference's ops
@@ -313,7 +351,9 @@ def make_oracle_fixtures():
 
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["reference", "select", "matching", "pack", "oracle"]
+    which = sys.argv[1:] or ["reference", "select", "matching", "voxelize", "pack", "oracle"]
+    if "voxelize" in which:
+        make_voxelize_fixtures()
     if "matching" in which:
         make_matching_fixtures()
     if "pack" in which:

@@ -866,3 +866,60 @@ def test_threshold_and_topk_empty_inputs_and_errors(ext):
         ext.threshold_select(torch.zeros((4, 4), device=DEV), 0.0)
     with pytest.raises(RuntimeError, match="CUDA"):
         ext.threshold_select(torch.zeros((4, 4)), 0.0, num_out=cnt)
+
+
+# ------------------------------------------------------------------------------------------------------
+# voxelisation (ops/voxelize.py) on the grid-subsampling kernels
+# ------------------------------------------------------------------------------------------------------
+def test_voxelize_vs_reference_fixture(ext, golden):
+    from vision3d_amd import ops
+
+    g = golden("ref_voxelize.npz")
+    pts, lengths, feats = T(g["points"]), T(g["lengths"]), T(g["feats"])
+    v, n, f, l = ops.voxelize_pack_mode(pts, lengths, float(g["voxel_size"]), feats=feats)
+    assert v.dtype == torch.long and np.array_equal(N_(v), g["voxels"])
+    assert np.array_equal(N_(l), g["v_lengths"])
+    assert np.array_equal(N_(n), g["nodes"]) and np.array_equal(N_(f), g["v_feats"])  # ordered sums: bit-exact
+    v2, n2, l2 = ops.voxelize_pack_mode(pts, lengths, float(g["voxel_size"]))
+    assert torch.equal(v, v2) and torch.equal(n, n2) and torch.equal(l, l2)
+    bv, bn, bf, bm = ops.voxelize(T(g["b_points"]), 0.25, masks=T(g["b_masks"]), feats=T(g["b_feats"]))
+    assert np.array_equal(N_(bm), g["b_v_masks"]) and np.array_equal(N_(bv), g["b_voxels"])
+    assert np.array_equal(N_(bn), g["b_nodes"]) and np.array_equal(N_(bf), g["b_v_feats"])
+    bv3, bn3, bm3 = ops.voxelize(T(g["b_points"]), 0.25)  # no masks, no features
+    assert bv3.shape[0] == 3 and bv3.shape[:2] == bm3.shape and bn3.shape == bv3.shape
+
+
+@pytest.mark.parametrize("case", ["random", "duplicates", "single_voxel", "ragged", "c4"])
+def test_voxelize_vs_oracle(ext, oracle_mod, case):
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(["random", "duplicates", "single_voxel", "ragged", "c4"].index(case) + 77)
+    if case == "random":
+        lengths, vs, C = [5000, 3000], 0.05, 16
+        pts = rng.random((8000, 3)).astype(np.float32)
+    elif case == "duplicates":
+        lengths, vs, C = [600, 600], 0.1, 3
+        pts = np.repeat(rng.random((400, 3)).astype(np.float32), 3, axis=0)
+    elif case == "single_voxel":
+        lengths, vs, C = [1000], 10.0, 5
+        pts = rng.random((1000, 3)).astype(np.float32)
+    elif case == "ragged":
+        lengths, vs, C = [1, 0, 257, 0, 4095, 2], 0.07, 1
+        pts = (rng.random((sum(lengths), 3)).astype(np.float32) - 0.5) * 4
+    else:  # config 4: 16 clouds of 30,000 points in a 3 x 3 x 2.5 m box, 2.5 cm voxels
+        lengths, vs, C = [30000] * 16, 0.025, 32
+        pts = rng.random((480000, 3)).astype(np.float32) * np.float32([3.0, 3.0, 2.5])
+    feats = rng.standard_normal((pts.shape[0], C)).astype(np.float32)
+    want = oracle_mod.voxelize_pack(pts, np.asarray(lengths), vs, feats)
+    got = ops.voxelize_pack_mode(T(pts), T(np.asarray(lengths, dtype=np.int64)), vs, feats=T(feats))
+    for w, g_, name in zip(want, got, ("voxels", "nodes", "v_feats", "v_lengths")):
+        assert np.array_equal(N_(g_), w), (case, name)
+    # consistency with grid subsampling where floor(p / v) == floor(p * (1 / v)): same voxel count per cloud
+    assert int(got[3].sum()) == got[0].shape[0]
+
+
+def test_voxelize_empty(ext):
+    from vision3d_amd import ops
+
+    v, n, l = ops.voxelize_pack_mode(torch.empty((0, 3), device=DEV), torch.zeros(2, dtype=torch.long, device=DEV), 0.1)
+    assert v.shape == (0, 3) and n.shape == (0, 3) and N_(l).tolist() == [0, 0]

@@ -147,6 +147,9 @@ def test_next_row_ops_signatures_and_no_cpu_path():
         # ops/matching.py:65, :90-92
         "extract_correspondences_from_scores_threshold": ["score_mat", "threshold", "return_score"],
         "extract_correspondences_from_scores_topk": ["score_mat", "k", "has_dustbin", "largest", "return_score"],
+        # ops/voxelize.py:6, :66
+        "voxelize_pack_mode": ["points", "lengths", "voxel_size", "feats"],
+        "voxelize": ["points", "voxel_size", "masks", "feats"],
         # ops/point_cloud_partition.py:41-48, :108-114
         "point_to_node_partition": ["points", "nodes", "point_limit", "return_count", "gather_points", "inf"],
         "ball_query_partition": ["points", "nodes", "radius", "point_limit", "return_count"],
@@ -163,6 +166,7 @@ def test_next_row_ops_signatures_and_no_cpu_path():
     for call in (lambda: ops.mutual_topk_select(torch.zeros(4, 4), 1),
                  lambda: ops.extract_correspondences_from_feats(f, f),
                  lambda: ops.extract_correspondences_from_scores_threshold(f, 0.1),
+                 lambda: ops.voxelize_pack_mode(torch.zeros(5, 3), torch.tensor([5]), 0.1),
                  lambda: ops.extract_correspondences_from_scores_topk(f, 3),
                  lambda: ops.SuperPointMatchingGlobalTopk(4)(f, f),
                  lambda: ops.SuperPointMatchingMutualTopk(4, 1)(f, f),

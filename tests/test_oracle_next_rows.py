@@ -112,3 +112,12 @@ def test_global_topk_oracle_tie_rule_and_range(oracle_mod):
     assert list(zip(r, c)) == [(2, 1), (0, 0), (0, 1), (0, 2)]  # equal scores: ascending flat index
     with pytest.raises(RuntimeError, match="out of range"):
         oracle_mod.extract_correspondences_from_scores_topk(s, 13)
+
+
+def test_voxelize_oracle_matches_reference_fixture(oracle_mod, golden):
+    """ops/voxelize.py:6-63 run on the CPU -> ref_voxelize.npz; bit-exact (sequential sums in input order)."""
+    g = golden("ref_voxelize.npz")
+    v, n, f, l = oracle_mod.voxelize_pack(g["points"], g["lengths"], float(g["voxel_size"]), g["feats"])
+    assert np.array_equal(v, g["voxels"]) and np.array_equal(l, g["v_lengths"])
+    assert np.array_equal(n, g["nodes"]) and np.array_equal(f, g["v_feats"])
+    assert int(g["lengths"][1]) == 0 and int(l[1]) == 0  # the empty cloud stays empty

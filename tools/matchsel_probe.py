@@ -14,7 +14,10 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n * 1e3
 
 dev = "cuda:0"
-for n, k in ((512, 256), (2048, 256), (8192, 256), (8192, 5000), (16384, 256)):
+CASES = ((512, 256), (2048, 256), (8192, 256), (8192, 5000), (16384, 256))
+if len(sys.argv) > 2:
+    CASES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for n, k in CASES:
     s = torch.randn((n, n), device=dev)
     idx = torch.empty((2, max(k, 1 << 20)), dtype=torch.long, device=dev)
     sc = torch.empty((max(k, 1 << 20),), device=dev)

@@ -57,6 +57,8 @@ SIGNATURES = {
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64] + _WS + _TAIL),
     "v3d_topk_merge_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_int] + _TAIL),
     "v3d_grid_subsample_pack_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_f32] + _TAIL),
+    "v3d_voxelize_pack_f32": (
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_f32] + _TAIL),
     "v3d_radius_search_workspace_bytes": (_c_size, [_c_int, _c_i64]),
     "v3d_radius_search_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32, _c_int] + _WS + _TAIL),

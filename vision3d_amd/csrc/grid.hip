@@ -4,6 +4,10 @@
 // (float atomics on CUDA) -> divide -> bincount.  Same result definition: one point per occupied voxel = mean of the
 // voxel's points, output ordered by (cloud, vx, vy, vz) like torch.unique of the hash.
 //
+// `voxelize_pack_mode` (vision3d/ops/voxelize.py:6-63) is the same reduction with three more outputs -- the integer voxel
+// coordinates, the voxel means of an optional (N,C) feature tensor, and floor(p / voxel) instead of floor(p * (1/voxel)) --
+// and runs on the same kernels (`v3d_voxelize_pack_f32`).
+//
 // Design (gfx950): keys (cloud | vx | vy | vz, 10 + 3 x 18 bits) are sorted with ONE stable device radix sort
 // (rocPRIM -- a plain library primitive, like a GEMM from hipBLASLt) carrying the point index as the value, so equal
 // voxels stay in input order; a head flag + exclusive scan gives every voxel its output slot; one thread per voxel
@@ -23,7 +27,11 @@ constexpr int kGsThreads = 256;
 constexpr int kGsMaxClouds = 1024;       // 10 key bits
 constexpr int kGsCoordBits = 18;         // voxel coordinates relative to the cloud's minimum: < 262,144 per axis
 
-__device__ __forceinline__ int gs_voxel(float p, float inv) { return (int)floorf(p * inv); }  // :64-65
+// scale > 0: floor(p * scale), grid_subsample.py:64-65 (scale = 1 / voxel_size rounded to fp32);
+// scale < 0: floor(p / -scale), voxelize.py:22 (correctly rounded fp32 division)
+__device__ __forceinline__ int gs_voxel(float p, float scale) {
+  return (int)floorf(scale > 0.f ? p * scale : p / -scale);
+}
 
 // One workgroup per cloud: its first point and its minimum voxel (grid_subsample.py:75).
 __global__ __launch_bounds__(kGsThreads) void gs_minvox_kernel(const float* __restrict__ pts,
@@ -96,11 +104,24 @@ __global__ __launch_bounds__(kGsThreads) void gs_reduce_kernel(const float* __re
                                                                const int* __restrict__ flags,
                                                                const int* __restrict__ slots, const int* __restrict__ error,
                                                                float* __restrict__ out, int64_t* __restrict__ num_out,
-                                                               long long total) {
+                                                               long long total,
+                                                               const unsigned long long* __restrict__ keys,
+                                                               const int* __restrict__ minv,
+                                                               int64_t* __restrict__ out_voxels,
+                                                               int* __restrict__ head_pos) {
   const long long i = (long long)blockIdx.x * kGsThreads + threadIdx.x;
   if (i >= total) return;
   if (i == total - 1) *num_out = *error ? -1 : (int64_t)slots[i] + flags[i];
   if (!flags[i]) return;
+  if (head_pos) head_pos[slots[i]] = (int)i;
+  if (out_voxels) {  // voxelize.py:43-44: the voxel's integer coordinates
+    const unsigned long long key = keys[i];
+    const int b = (int)(key >> (3 * kGsCoordBits));
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      out_voxels[(long long)slots[i] * 3 + a] =
+          (int64_t)((key >> ((2 - a) * kGsCoordBits)) & ((1ull << kGsCoordBits) - 1)) + (int64_t)minv[b * 3 + a];
+  }
   float sx = 0.f, sy = 0.f, sz = 0.f;
   long long j = i;
   do {
@@ -115,6 +136,27 @@ __global__ __launch_bounds__(kGsThreads) void gs_reduce_kernel(const float* __re
   out[m * 3 + 0] = sx / c;
   out[m * 3 + 1] = sy / c;
   out[m * 3 + 2] = sz / c;
+}
+
+// Voxel means of a feature tensor (voxelize.py:57-60): thread = (voxel, channel), the voxel's points summed in input
+// order like the coordinates; consecutive threads read consecutive channels of a row.
+__global__ __launch_bounds__(kGsThreads) void gs_feats_kernel(const float* __restrict__ feats, const int* __restrict__ vals,
+                                                              const int* __restrict__ flags,
+                                                              const int* __restrict__ head_pos,
+                                                              const int64_t* __restrict__ num_out, int C, long long total,
+                                                              float* __restrict__ out_feats) {
+  const long long t = (long long)blockIdx.x * kGsThreads + threadIdx.x;
+  const long long m = t / C;
+  const int c = (int)(t % C);
+  if (m >= *num_out) return;  // also covers the error value -1
+  long long j = head_pos[m];
+  const long long first = j;
+  float sum = 0.f;
+  do {
+    sum += feats[(long long)vals[j] * C + c];
+    ++j;
+  } while (j < total && !flags[j]);
+  out_feats[m * C + c] = sum / (float)(j - first);
 }
 
 // Per-cloud counts without atomics: the first record of a cloud is a voxel head, so the exclusive head count there is
@@ -140,17 +182,16 @@ __global__ void gs_lengths_kernel(const unsigned long long* __restrict__ keys, c
 
 }  // namespace v3d
 
-extern "C" {
-
-int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, float* sampled_points,
-                                int64_t* sampled_lengths, int64_t* num_sampled, int B, int64_t total, float voxel_size,
-                                int device, void* stream_) {
-  using namespace v3d;
-  const char* what = "grid_subsample_pack_mode";
+namespace v3d {
+static int grid_reduce(const char* what, const float* points, const int64_t* lengths, const float* feats, int C,
+                       float* sampled_points, int64_t* out_voxels, float* out_feats, int64_t* sampled_lengths,
+                       int64_t* num_sampled, int B, int64_t total, float voxel_size, bool divide, int device,
+                       void* stream_) {
   V3D_REQUIRE(B >= 0 && total >= 0, what, "negative dimension");
   V3D_REQUIRE(voxel_size > 0.f, what, "voxel_size must be positive");  // NaN fails too
   V3D_REQUIRE(num_sampled && (B == 0 || (lengths && sampled_lengths)) && (total == 0 || (points && sampled_points)),
               what, "null pointer");
+  V3D_REQUIRE(C >= 0 && (C == 0 || total == 0 || (feats && out_feats)), what, "feature buffers missing");
   if (B > kGsMaxClouds || total >= (int64_t)INT32_MAX) {
     set_last_error("%s: at most %d clouds and 2^31-1 points per call", what, kGsMaxClouds);
     return V3D_ERR_SIZE_LIMIT;
@@ -161,7 +202,8 @@ int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, flo
   if (B > 0) V3D_HIP_TRY(hipMemsetAsync(sampled_lengths, 0, sizeof(int64_t) * (size_t)B, stream), what);
   V3D_HIP_TRY(hipMemsetAsync(num_sampled, 0, sizeof(int64_t), stream), what);
   if (total == 0 || B == 0) return 0;
-  const float inv = (float)(1.0 / (double)voxel_size);  // :64: a Python float, rounded to float32 by the product
+  // :64: 1 / voxel_size is a Python float, rounded to float32 by the product; voxelize.py:22 divides instead
+  const float inv = divide ? -voxel_size : (float)(1.0 / (double)voxel_size);
 
   const size_t n = (size_t)total;
   size_t sort_bytes = 0, scan_bytes = 0;
@@ -178,7 +220,8 @@ int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, flo
   };
   const size_t o_off = take(sizeof(long long) * ((size_t)B + 1)), o_min = take(sizeof(int) * 3 * (size_t)B),
                o_err = take(sizeof(int)), o_k0 = take(8 * n), o_k1 = take(8 * n), o_v0 = take(4 * n), o_v1 = take(4 * n),
-               o_flag = take(4 * n), o_slot = take(4 * n), o_tmp = take(std::max(sort_bytes, scan_bytes));
+               o_flag = take(4 * n), o_slot = take(4 * n), o_head = take(C > 0 ? 4 * n : 0),
+               o_tmp = take(std::max(sort_bytes, scan_bytes));
   char* base = nullptr;
   V3D_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), off, stream), what);
   long long* offsets = reinterpret_cast<long long*>(base + o_off);
@@ -190,6 +233,7 @@ int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, flo
   int* v1 = reinterpret_cast<int*>(base + o_v1);
   int* flags = reinterpret_cast<int*>(base + o_flag);
   int* slots = reinterpret_cast<int*>(base + o_slot);
+  int* head_pos = C > 0 ? reinterpret_cast<int*>(base + o_head) : nullptr;
   void* tmp = base + o_tmp;
   int rc = 0;
   do {
@@ -217,7 +261,10 @@ int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, flo
       break;
     }
     hipLaunchKernelGGL(gs_reduce_kernel, dim3(blocks), dim3(kGsThreads), 0, stream, points, v1, flags, slots, error,
-                       sampled_points, num_sampled, (long long)total);
+                       sampled_points, num_sampled, (long long)total, k1, minv, out_voxels, head_pos);
+    if (C > 0)
+      hipLaunchKernelGGL(gs_feats_kernel, dim3((unsigned)ceil_div(total * C, kGsThreads)), dim3(kGsThreads), 0, stream,
+                         feats, v1, flags, head_pos, num_sampled, C, (long long)total, out_feats);
     hipLaunchKernelGGL(gs_lengths_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, stream, k1, flags, slots,
                        sampled_lengths, B, (long long)total);
     rc = launch_status(what);
@@ -228,6 +275,30 @@ int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, flo
     rc = (int)e;
   }
   return rc;
+}
+}  // namespace v3d
+
+extern "C" {
+
+int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, float* sampled_points,
+                                int64_t* sampled_lengths, int64_t* num_sampled, int B, int64_t total, float voxel_size,
+                                int device, void* stream) {
+  return v3d::grid_reduce("grid_subsample_pack_mode", points, lengths, nullptr, 0, sampled_points, nullptr, nullptr,
+                          sampled_lengths, num_sampled, B, total, voxel_size, false, device, stream);
+}
+
+int v3d_voxelize_pack_f32(const float* points, const int64_t* lengths, const float* feats, int C, int64_t* voxels,
+                          float* nodes, float* voxel_feats, int64_t* voxel_lengths, int64_t* num_voxels, int B,
+                          int64_t total, float voxel_size, int device, void* stream) {
+  using namespace v3d;
+  const char* what = "voxelize_pack_mode";
+  V3D_REQUIRE(total <= 0 || voxels, what, "null pointer");
+  if (C > 0 && total > 0 && total * (int64_t)C >= ((int64_t)INT32_MAX - 1) * kGsThreads) {
+    set_last_error("%s: total * C too large for one launch", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  return grid_reduce(what, points, lengths, feats, C, nodes, voxels, voxel_feats, voxel_lengths, num_voxels, B, total,
+                     voxel_size, true, device, stream);
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
 
 #include "common.h"
 
@@ -153,6 +154,8 @@ __global__ __launch_bounds__(1024) void ms_thr_small_kernel(const float* __restr
 }
 
 // ---- global top-k -----------------------------------------------------------------------------------------------
+constexpr int kMsSamples = 8192;  // keys of the pivot sample (32 KiB of LDS)
+
 struct MsState {
   unsigned key;        // resolved high bits of the k-th best key T
   unsigned cell;       // resolved high bits of the last cell taken among the cells equal to T
@@ -160,9 +163,11 @@ struct MsState {
   unsigned all_equal;  // 1: every cell equal to T is taken -- the three index passes return at once
   unsigned taken;      // append cursor of the last pass
   unsigned ticket[6];
-  unsigned pad;
+  unsigned pivot;      // sampled key bound of the short list
+  unsigned listed;     // cells with key <= pivot (all of them, also past the list's capacity)
+  unsigned pad[3];
 };
-static_assert(sizeof(MsState) == 48, "MsState layout");
+static_assert(sizeof(MsState) == 64, "MsState layout");
 
 __device__ __forceinline__ void ms_pass_bits(int pass, int& shift, unsigned& mask) {
   const int p = pass % 3;
@@ -170,16 +175,178 @@ __device__ __forceinline__ void ms_pass_bits(int pass, int& shift, unsigned& mas
   mask = p == 2 ? 1023u : 2047u;
 }
 
+// Short list (k << N*M).  ONE workgroup reads 8192 jittered, evenly spread cells and finds the rank-th smallest key of
+// the sample by an 8-bit radix select in LDS: the pivot.  `rank` is chosen on the host so that the k-th best cell of the
+// matrix is below the pivot with overwhelming probability and about rank/8192 of all cells are.
+__global__ __launch_bounds__(1024) void ms_sample_kernel(const float* __restrict__ score, int64_t total, int largest,
+                                                         unsigned rank, MsState* __restrict__ st) {
+  __shared__ unsigned keys[kMsSamples];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_rem;
+  const int tid = threadIdx.x;
+  const int64_t stride = total / kMsSamples;  // >= 32 (host)
+#pragma unroll
+  for (int u = 0; u < kMsSamples / 1024; ++u) {
+    const unsigned i = (unsigned)(tid + u * 1024);
+    const unsigned mix = (i * 2654435761u) ^ ((i * 2246822519u) >> 13);
+    keys[i] = ms_key(score[(int64_t)i * stride + (int64_t)(mix % (unsigned long long)stride)], largest != 0);
+  }
+  unsigned prefix = 0, rem = rank;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kMsSamples / 1024; ++u) {
+      const unsigned key = keys[tid + u * 1024];
+      if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // lane l owns bins 4l .. 4l+3
+      unsigned c[4], mine = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        c[u] = hist[tid * 4 + u];
+        mine += c[u];
+      }
+      unsigned incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d, 64);
+        if (tid >= d) incl += t;
+      }
+      const unsigned before = incl - mine;
+      if (before < rem && rem <= incl) {  // exactly one lane
+        unsigned run = before;
+        int u = 0;
+        while (run + c[u] < rem) run += c[u++];
+        s_prefix = prefix | ((unsigned)(tid * 4 + u) << shift);
+        s_rem = rem - run;
+      }
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    rem = s_rem;
+    __syncthreads();
+  }
+  if (tid == 0) st->pivot = prefix;
+}
+
+// one atomic per wave: every lane's first slot for its `mine` entries
+__device__ __forceinline__ unsigned ms_wave_append(unsigned* cursor, int mine) {
+  const int lane = threadIdx.x & 63;
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  const int wave_sum = __shfl(incl, 63, 64);
+  unsigned first = 0;
+  if (wave_sum) {
+    if (lane == 0) first = atomicAdd(cursor, (unsigned)wave_sum);
+    first = __shfl(first, 0, 64);
+  }
+  return first + (unsigned)(incl - mine);
+}
+
+// Workgroup-buffered append: hits collect in LDS and reach the global list through ONE atomic per flush instead of one
+// per wave and step (65k atomics on one address cost more than reading a 256 MiB matrix).  Entries that find the LDS
+// buffer full go to the global list directly (one more wave-wide atomic); a flush happens when the buffer is half full.
+constexpr int kMsBuf = 2048;
+struct MsAppender {
+  unsigned long long buf[kMsBuf];
+  unsigned count, base;
+};
+__device__ __forceinline__ void ms_push16(MsAppender& A, const unsigned long long (&w)[16], unsigned hits,
+                                          unsigned* cursor, unsigned long long* __restrict__ out, unsigned cap) {
+  if (!__any(hits != 0)) return;
+  const int mine = __builtin_popcount(hits);
+  unsigned at = ms_wave_append(&A.count, mine);
+  const int over = (int)min((unsigned)mine, at + mine > (unsigned)kMsBuf ? at + mine - max(at, (unsigned)kMsBuf) : 0u);
+  unsigned gat = 0;
+  if (__any(over != 0)) gat = ms_wave_append(cursor, over);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (hits & (1u << j)) {
+      if (at < (unsigned)kMsBuf) {
+        A.buf[at] = w[j];
+      } else {
+        if (gat < cap) out[gat] = w[j];
+        ++gat;
+      }
+      ++at;
+    }
+  }
+}
+// all threads of the workgroup; returns the first global slot of this flush (the caller's overflow test)
+__device__ __forceinline__ unsigned ms_flush(MsAppender& A, unsigned* cursor, unsigned long long* __restrict__ out,
+                                             unsigned cap) {
+  __syncthreads();
+  const unsigned n = min(A.count, (unsigned)kMsBuf);
+  if (threadIdx.x == 0) A.base = n ? atomicAdd(cursor, n) : 0u;
+  __syncthreads();
+  const unsigned base = A.base;
+  for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+    if (base + i < cap) out[base + i] = A.buf[i];
+  __syncthreads();
+  if (threadIdx.x == 0) A.count = 0;
+  __syncthreads();
+  return base + n;
+}
+
+// The one full read of the short-list route: cells with key <= pivot become (key << 32 | cell) words.
+__global__ __launch_bounds__(512) void ms_list_kernel(const float* __restrict__ score, int64_t total, int largest, int vec,
+                                                      MsState* __restrict__ st, unsigned long long* __restrict__ list,
+                                                      unsigned list_cap) {
+  __shared__ MsAppender A;
+  if (threadIdx.x == 0) A.count = 0;
+  __syncthreads();
+  const unsigned pivot = st->pivot;
+  const int64_t stride = (int64_t)gridDim.x * 512 * 16;
+  for (int64_t first = (int64_t)blockIdx.x * 512 * 16; first < total; first += stride) {  // uniform over the workgroup
+    const int64_t base = first + (int64_t)threadIdx.x * 16;
+    float v[16];
+    ms_load16(score, base, total, vec != 0, 0.f, v);
+    unsigned long long w[16];
+    unsigned hits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const unsigned key = ms_key(v[j], largest != 0);
+      hits |= ((base + j < total && key <= pivot) ? 1u : 0u) << j;
+      w[j] = ((unsigned long long)key << 32) | (unsigned)(base + j);
+    }
+    ms_push16(A, w, hits, &st->listed, list, list_cap);
+    __syncthreads();
+    if (A.count >= (unsigned)kMsBuf / 2 && ms_flush(A, &st->listed, list, list_cap) > list_cap)
+      return;  // the list has overflowed (ties, or a pivot that admits too much): it will be ignored, stop feeding it
+  }
+  (void)ms_flush(A, &st->listed, list, list_cap);
+}
+
+// The selection runs on the short list when it holds the answer: at least k cells, none lost to the capacity.
+__device__ __forceinline__ bool ms_use_list(const MsState* st, unsigned k, unsigned list_cap) {
+  return list_cap != 0 && st->listed >= k && st->listed <= list_cap;
+}
+
 // pass 0..2: histogram of the next key bits over the cells whose higher key bits equal state.key;
 // pass 3..5: histogram of the next CELL-INDEX bits over the cells with key == T whose higher index bits match.
+// Source: the short list if it is valid, else the matrix.
 __global__ __launch_bounds__(512) void ms_hist_kernel(const float* __restrict__ score, int64_t total, int largest, int vec,
                                                       int pass, unsigned k, MsState* __restrict__ st,
-                                                      unsigned* __restrict__ hist) {
+                                                      unsigned* __restrict__ hist,
+                                                      const unsigned long long* __restrict__ list, unsigned list_cap) {
   __shared__ unsigned h[kMsBins];
   __shared__ unsigned wave_tot[8];
   __shared__ int is_last;
   const unsigned skey = st->key, scell = st->cell;
   if (pass >= 3 && st->all_equal) return;  // uniform over the grid: written by the pass-2 pick before this launch began
+  // The grid is sized for the matrix.  On the short list only a few workgroups take part: each one ends with same-address
+  // global atomics (histogram flush, ticket) that serialise in the L2 -- 256 workgroups spent 30 us per pass there, on a
+  // list that sixteen read in five.
+  const bool on_list = ms_use_list(st, k, list_cap);
+  const unsigned nblk = on_list ? min(gridDim.x, max(1u, st->listed / (512u * 16u))) : gridDim.x;
+  if (blockIdx.x >= nblk) return;
   int shift;
   unsigned mask;
   ms_pass_bits(pass, shift, mask);
@@ -187,24 +354,42 @@ __global__ __launch_bounds__(512) void ms_hist_kernel(const float* __restrict__ 
   for (int i = threadIdx.x; i < kMsBins; i += 512) h[i] = 0;
   __syncthreads();
   unsigned* gh = hist + (size_t)pass * kMsBins;
-  const int64_t stride = (int64_t)gridDim.x * 512 * 16;
-  for (int64_t base = ((int64_t)blockIdx.x * 512 + threadIdx.x) * 16; base < total; base += stride) {
-    float v[16];
-    ms_load16(score, base, total, vec != 0, 0.f, v);
+  auto count = [&](unsigned key, unsigned cell, bool valid) {  // called by whole waves (ballots inside)
+    bool on;
+    unsigned bin;
+    if (pass < 3) {
+      on = hi >= 32 || (key >> hi) == (skey >> hi);
+      bin = (key >> shift) & mask;
+    } else {
+      on = key == skey && (hi >= 32 || (cell >> hi) == (scell >> hi));
+      bin = (cell >> shift) & mask;
+    }
+    on = on && valid;
+    // keys under one pivot share their high bits, tied scores share all of them: when every counting lane of the wave
+    // names the same bin, one lane adds the count (same-address LDS atomics serialise)
+    const unsigned long long voters = __ballot(on);
+    if (voters == 0) return;
+    const unsigned bin0 = (unsigned)__shfl((int)bin, __builtin_ctzll(voters), 64);
+    if (__ballot(on && bin != bin0) == 0) {
+      if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(voters)) atomicAdd(&h[bin0], (unsigned)__builtin_popcountll(voters));
+    } else if (on) {
+      atomicAdd(&h[bin], 1u);
+    }
+  };
+  if (on_list) {
+    const unsigned n = st->listed;
+    for (unsigned i0 = blockIdx.x * 512; i0 < n; i0 += nblk * 512) {
+      const unsigned i = i0 + threadIdx.x;
+      const unsigned long long w = i < n ? list[i] : 0ull;
+      count((unsigned)(w >> 32), (unsigned)w, i < n);
+    }
+  } else {
+    const int64_t stride = (int64_t)gridDim.x * 512 * 16;
+    for (int64_t base = ((int64_t)blockIdx.x * 512 + threadIdx.x) * 16; __any(base < total); base += stride) {
+      float v[16];
+      ms_load16(score, base, total, vec != 0, 0.f, v);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (base + j >= total) break;
-      const unsigned key = ms_key(v[j], largest != 0), cell = (unsigned)(base + j);
-      bool on;
-      unsigned bin;
-      if (pass < 3) {
-        on = hi >= 32 || (key >> hi) == (skey >> hi);
-        bin = (key >> shift) & mask;
-      } else {
-        on = key == skey && (hi >= 32 || (cell >> hi) == (scell >> hi));
-        bin = (cell >> shift) & mask;
-      }
-      if (on) atomicAdd(&h[bin], 1u);
+      for (int j = 0; j < 16; ++j) count(ms_key(v[j], largest != 0), (unsigned)(base + j), base + j < total);
     }
   }
   __syncthreads();
@@ -212,7 +397,7 @@ __global__ __launch_bounds__(512) void ms_hist_kernel(const float* __restrict__ 
     if (h[i]) atomicAdd(&gh[i], h[i]);
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) is_last = atomicAdd(&st->ticket[pass], 1u) == gridDim.x - 1 ? 1 : 0;
+  if (threadIdx.x == 0) is_last = atomicAdd(&st->ticket[pass], 1u) == nblk - 1 ? 1 : 0;
   __syncthreads();
   if (!is_last) return;
   __threadfence();
@@ -257,40 +442,43 @@ __global__ __launch_bounds__(512) void ms_hist_kernel(const float* __restrict__ 
 // cells with key < T, and cells with key == T up to cell index `state.cell`, are the k winners
 __global__ __launch_bounds__(512) void ms_take_kernel(const float* __restrict__ score, int64_t total, int largest, int vec,
                                                       unsigned k, MsState* __restrict__ st,
-                                                      unsigned long long* __restrict__ cand) {
+                                                      unsigned long long* __restrict__ cand,
+                                                      const unsigned long long* __restrict__ list, unsigned list_cap) {
   const unsigned T = st->key, tcell = st->cell;
-  const int lane = threadIdx.x & 63;
+  const unsigned long long bound = ((unsigned long long)T << 32) | tcell;  // words compare like (key, cell) pairs
+  if (ms_use_list(st, k, list_cap)) {
+    const unsigned n = st->listed;
+    const unsigned nblk = min(gridDim.x, max(1u, n / (512u * 16u)));
+    if (blockIdx.x >= nblk) return;
+    for (unsigned i0 = blockIdx.x * 512; i0 < n; i0 += nblk * 512) {
+      const unsigned i = i0 + threadIdx.x;
+      const unsigned long long w = i < n ? list[i] : ~0ull;
+      const bool on = i < n && w <= bound;
+      const unsigned at = ms_wave_append(&st->taken, on ? 1 : 0);
+      if (on && at < k) cand[at] = w;
+    }
+    return;
+  }
+  __shared__ MsAppender A;
+  if (threadIdx.x == 0) A.count = 0;
+  __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * 512 * 16;
-  for (int64_t base = ((int64_t)blockIdx.x * 512 + threadIdx.x) * 16; __any(base < total); base += stride) {
+  for (int64_t first = (int64_t)blockIdx.x * 512 * 16; first < total; first += stride) {  // uniform over the workgroup
+    const int64_t base = first + (int64_t)threadIdx.x * 16;
     float v[16];
     ms_load16(score, base, total, vec != 0, 0.f, v);
-    unsigned key[16], hits = 0;
+    unsigned long long w[16];
+    unsigned hits = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      key[j] = ms_key(v[j], largest != 0);
-      const unsigned cell = (unsigned)(base + j);
-      const bool on = base + j < total && (key[j] < T || (key[j] == T && cell <= tcell));
-      hits |= (on ? 1u : 0u) << j;
+      w[j] = ((unsigned long long)ms_key(v[j], largest != 0) << 32) | (unsigned)(base + j);
+      hits |= ((base + j < total && w[j] <= bound) ? 1u : 0u) << j;
     }
-    // one atomic per wave: lane prefix of the hit counts
-    const int mine = __builtin_popcount(hits);
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
-    const int wave_sum = __shfl(incl, 63, 64);
-    unsigned first = 0;
-    if (wave_sum) {
-      if (lane == 0) first = atomicAdd(&st->taken, (unsigned)wave_sum);
-      first = __shfl(first, 0, 64);
-    }
-    unsigned at = first + (unsigned)(incl - mine);
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if ((hits & (1u << j)) && at < k) cand[at++] = ((unsigned long long)key[j] << 32) | (unsigned)(base + j);
+    ms_push16(A, w, hits, &st->taken, cand, k);
+    __syncthreads();
+    if (A.count >= (unsigned)kMsBuf / 2) (void)ms_flush(A, &st->taken, cand, k);
   }
+  (void)ms_flush(A, &st->taken, cand, k);
 }
 
 // k <= 4096 winners: bitonic sort in LDS, dustbin filter, scan, emit -- one workgroup
@@ -480,7 +668,22 @@ int v3d_global_topk_select_f32(const float* score, int64_t N, int64_t M, int64_t
   };
   const size_t o_state = take(sizeof(MsState)), o_hist = take(6 * kMsBins * sizeof(unsigned));
   const size_t zero_bytes = off;
+  // Short-list route (k a small fraction of the matrix): rank of the pivot in the 8192-cell sample = expected number of
+  // sampled cells among the k best, plus six standard deviations, plus 16; the list holds three times the expected
+  // number of cells under the pivot.  Whatever the data does (ties, adversarial layouts), a list that overflows or holds
+  // fewer than k cells is ignored and the selection reads the matrix: the route changes the speed, never the result.
+  unsigned rank = 0, list_cap = 0;
+  if (total >= (int64_t)kMsSamples * 128) {
+    const double expect = (double)kMsSamples * (double)k / (double)total;
+    const double r = std::ceil(expect + 6.0 * std::sqrt(expect) + 16.0);
+    const double cap = 3.0 * r * (double)total / kMsSamples + 4096.0;
+    if (r <= kMsSamples / 24 && cap <= (double)total / 8) {
+      rank = (unsigned)r;
+      list_cap = (unsigned)cap;
+    }
+  }
   const size_t o_cand = take(8 * (size_t)k);
+  const size_t o_list = take(8 * (size_t)list_cap);
   const size_t o_sorted = small_sort ? 0 : take(8 * (size_t)k), o_keep = small_sort ? 0 : take(4 * (size_t)k),
                o_slot = small_sort ? 0 : take(4 * (size_t)k), o_tmp = small_sort ? 0 : take(std::max(sort_bytes, scan_bytes));
   char* base = nullptr;
@@ -495,12 +698,18 @@ int v3d_global_topk_select_f32(const float* score, int64_t N, int64_t M, int64_t
     MsState* st = reinterpret_cast<MsState*>(base + o_state);
     unsigned* hist = reinterpret_cast<unsigned*>(base + o_hist);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(base + o_cand);
+    unsigned long long* list = list_cap ? reinterpret_cast<unsigned long long*>(base + o_list) : nullptr;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 512 * 16), 2048));
+    if (list_cap) {
+      hipLaunchKernelGGL(ms_sample_kernel, dim3(1), dim3(1024), 0, stream, score, total, largest, rank, st);
+      hipLaunchKernelGGL(ms_list_kernel, dim3(blocks), dim3(512), 0, stream, score, total, largest, vec, st, list, list_cap);
+    }
+    const unsigned sel_blocks = blocks;
     for (int pass = 0; pass < 6; ++pass)
-      hipLaunchKernelGGL(ms_hist_kernel, dim3(blocks), dim3(512), 0, stream, score, total, largest, vec, pass, (unsigned)k,
-                         st, hist);
-    hipLaunchKernelGGL(ms_take_kernel, dim3(blocks), dim3(512), 0, stream, score, total, largest, vec, (unsigned)k, st,
-                       cand);
+      hipLaunchKernelGGL(ms_hist_kernel, dim3(sel_blocks), dim3(512), 0, stream, score, total, largest, vec, pass,
+                         (unsigned)k, st, hist, list, list_cap);
+    hipLaunchKernelGGL(ms_take_kernel, dim3(sel_blocks), dim3(512), 0, stream, score, total, largest, vec, (unsigned)k, st,
+                       cand, list, list_cap);
     if (small_sort) {
       hipLaunchKernelGGL(ms_sort_emit_small_kernel, dim3(1), dim3(1024), 0, stream, cand, (int)k, score, (int)N, (int)M,
                          dustbin, out_row, out_col, out_score, num_out, capacity);

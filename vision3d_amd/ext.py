@@ -31,6 +31,7 @@ __all__ = [
     "topk_merge",
     "radius_search_pack",
     "grid_subsample_pack",
+    "voxelize_pack",
     "mutual_topk_select",
     "mutual_select_lists",
     "threshold_select",
@@ -373,6 +374,39 @@ def grid_subsample_pack(points, lengths, sampled_points, sampled_lengths, num_sa
         points.data_ptr(), lengths.data_ptr(), sampled_points.data_ptr(), sampled_lengths.data_ptr(),
         num_sampled.data_ptr(), lengths.shape[0], points.shape[0], float(voxel_size), dev, stream)
     _lib.check(rc, "grid_subsample_pack_mode")
+
+
+def voxelize_pack(points, lengths, voxels, nodes, voxel_lengths, num_voxels, voxel_size, feats=None, voxel_feats=None):
+    """points (N,3) fp32, lengths (B,), optional feats (N,C) -> voxels (N,3) i64 / nodes (N,3) / voxel_feats (N,C)
+    capacity buffers, voxel_lengths (B,), num_voxels ()."""
+    for t, name in ((points, "points"), (lengths, "lengths"), (voxels, "voxels"), (nodes, "nodes"),
+                    (voxel_lengths, "voxel_lengths"), (num_voxels, "num_voxels")):
+        _check_cuda_contiguous(t, name)
+    _check_float(points, "points")
+    _check_float(nodes, "nodes")
+    for t, name in ((lengths, "lengths"), (voxels, "voxels"), (voxel_lengths, "voxel_lengths"),
+                    (num_voxels, "num_voxels")):
+        _check_long(t, name)
+    n = points.shape[0]
+    if voxels.shape[0] < n or nodes.shape[0] < n or voxel_lengths.shape[0] != lengths.shape[0]:
+        raise RuntimeError("voxelize_pack: output buffers too small")
+    C = 0
+    if feats is not None:
+        _check_cuda_contiguous(feats, "feats")
+        _check_float(feats, "feats")
+        if voxel_feats is None:
+            raise RuntimeError("voxelize_pack: voxel_feats is required with feats")
+        _check_cuda_contiguous(voxel_feats, "voxel_feats")
+        _check_float(voxel_feats, "voxel_feats")
+        C = feats.shape[1]
+        if feats.shape[0] != n or voxel_feats.shape[0] < n or voxel_feats.shape[1] != C:
+            raise RuntimeError("voxelize_pack: feats (N,C) / voxel_feats (N,C) do not match the points")
+    dev, stream = _where(points)
+    rc = _lib.lib().v3d_voxelize_pack_f32(
+        points.data_ptr(), lengths.data_ptr(), _ptr(feats) if C else None, C, voxels.data_ptr(), nodes.data_ptr(),
+        _ptr(voxel_feats) if C else None, voxel_lengths.data_ptr(), num_voxels.data_ptr(), lengths.shape[0], n,
+        float(voxel_size), dev, stream)
+    _lib.check(rc, "voxelize_pack_mode")
 
 
 # --------------------------------------------------------------------------------------------------------

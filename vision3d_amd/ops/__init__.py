@@ -26,6 +26,7 @@ from .point_cloud_partition import ball_query_partition, point_to_node_partition
 from .radius_search import radius_count_pack_mode, radius_search_pack_mode
 from .three_interpolate import three_interpolate
 from .three_nn import three_nn
+from .voxelize import voxelize, voxelize_pack_mode
 
 __all__ = [
     "ball_query", "batch_to_pack", "batch_to_pack_with_lengths", "pack_to_batch", "furthest_point_sample", "gather",
@@ -33,7 +34,7 @@ __all__ = [
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats", "extract_correspondences_from_scores",
     "extract_correspondences_from_scores_threshold", "extract_correspondences_from_scores_topk",
-    "SuperPointMatchingGlobalTopk", "SuperPointMatchingMutualTopk",
+    "SuperPointMatchingGlobalTopk", "SuperPointMatchingMutualTopk", "voxelize", "voxelize_pack_mode",
     "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
     "knn_interpolate_pack_mode", "sa_group", "edge_group", "kpconv_gather", "kpconv", "point_to_node_partition", "ball_query_partition",
 ]
