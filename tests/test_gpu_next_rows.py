@@ -923,3 +923,38 @@ def test_voxelize_empty(ext):
 
     v, n, l = ops.voxelize_pack_mode(torch.empty((0, 3), device=DEV), torch.zeros(2, dtype=torch.long, device=DEV), 0.1)
     assert v.shape == (0, 3) and n.shape == (0, 3) and N_(l).tolist() == [0, 0]
+
+
+def test_knn_interpolate_and_deprecated_spellings(ext):
+    """knn_interpolate (knn_interpolate.py:10-40) against the same lines written with torch on the device (the search
+    replaced by a brute-force cdist + topk); get_point_to_node_indices / naive_radius_search_pack_mode against the
+    functions they are spellings of."""
+    from vision3d_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q = torch.rand((3000, 3), device=DEV, generator=g)
+    s = torch.rand((1200, 3), device=DEV, generator=g)
+    for C in (32, 6):  # fused kernel / generic formulation
+        f = torch.randn((1200, C), device=DEV, generator=g, requires_grad=True)
+        for limit in (None, 0.05):
+            out = ops.knn_interpolate(q, s, f, k=3, distance_limit=limit)
+            d, i = torch.cdist(q.double(), s.double()).topk(3, dim=1, largest=False)
+            d = d.float()
+            if limit is not None:
+                d = d.masked_fill(d > limit, 1e10)
+            w = 1.0 / (d + 1e-10)
+            w = w / w.sum(dim=1, keepdim=True)
+            want = (f.detach()[i] * w.unsqueeze(-1)).sum(dim=1)
+            assert torch.allclose(out, want, rtol=1e-4, atol=1e-5), (C, limit)
+        up = torch.randn_like(out)
+        (grad,) = torch.autograd.grad(out, f, up)
+        want_grad = torch.zeros_like(f).index_add_(0, i.reshape(-1), (up.unsqueeze(1) * w.unsqueeze(-1)).reshape(-1, C))
+        assert torch.allclose(grad, want_grad, rtol=1e-4, atol=1e-5), C
+    nodes = s[:50].contiguous()
+    a, sizes = ops.get_point_to_node_indices(q, nodes, return_counts=True)
+    b = ops.point_to_node_partition(q, nodes, return_count=True, gather_points=False)
+    assert torch.equal(a, b[0]) and torch.equal(sizes, b[1]) and torch.equal(ops.get_point_to_node_indices(q, nodes), a)
+    ql = torch.tensor([1000, 2000], device=DEV)
+    sl = torch.tensor([500, 700], device=DEV)
+    assert torch.equal(ops.naive_radius_search_pack_mode(q, s, ql, sl, 0.1, 16),
+                       ops.radius_search_pack_mode(q, s, ql, sl, 0.1, 16))

@@ -159,6 +159,10 @@ def test_next_row_ops_signatures_and_no_cpu_path():
         "global_avgpool_pack_mode": ["feats", "lengths"],
         "nearest_interpolate_pack_mode": ["inputs", "neighbor_indices"],
         "knn_interpolate_pack_mode": ["q_points", "s_points", "s_feats", "neighbor_indices", "k", "eps"],
+        # ops/knn_interpolate.py:10-17, ops/point_cloud_partition.py:14, ops/radius_search.py:8
+        "knn_interpolate": ["q_points", "s_points", "s_feats", "k", "eps", "distance_limit"],
+        "get_point_to_node_indices": ["points", "nodes", "return_counts"],
+        "naive_radius_search_pack_mode": ["q_points", "s_points", "q_lengths", "s_lengths", "radius", "neighbor_limit"],
     }
     for name, args in expect.items():
         assert list(inspect.signature(getattr(ops, name)).parameters) == args, name
@@ -175,6 +179,8 @@ def test_next_row_ops_signatures_and_no_cpu_path():
                  lambda: ops.global_avgpool_pack_mode(f, torch.tensor([5])),
                  lambda: ops.nearest_interpolate_pack_mode(f, t),
                  lambda: ops.knn_interpolate_pack_mode(torch.zeros(3, 3), torch.zeros(5, 3), f, t),
+                 lambda: ops.knn_interpolate(torch.zeros(3, 3), torch.zeros(5, 3), f),
+                 lambda: ops.get_point_to_node_indices(torch.zeros(5, 3), torch.zeros(2, 3)),
                  lambda: ops.sa_group(torch.zeros(1, 3, 2), torch.zeros(1, 3, 5), None, torch.zeros(1, 2, 2, dtype=torch.long)),
                  lambda: ops.edge_group(torch.zeros(1, 4, 2), torch.zeros(1, 4, 5), torch.zeros(1, 2, 2, dtype=torch.long)),
                  lambda: ops.kpconv_gather(torch.zeros(3, 3), torch.zeros(5, 3), f, t, torch.zeros(15, 3), 0.1)):

@@ -143,6 +143,33 @@ def main():
         y = torch.nn.functional.normalize(torch.randn((m, c), generator=g), dim=1).to(DEV)
         add(f"mutual_nn_from_feats N{n} M{m} C{c}",
             lambda x=x, y=y: ops.extract_correspondences_from_feats(x, y, mutual=True), 4.0 * n * m * c / 1e6, "TFLOP/s")
+    # ---- the other selectors of ops/matching.py: threshold selection and global top-k (native vs torch formulation) ----
+    for (n, k) in ((512, 256), (2048, 256), (8192, 256), (16384, 256)):
+        score = torch.randn((n, n), generator=g).to(DEV)
+        idx = torch.empty((2, 1 << 20), dtype=torch.long, device=DEV)
+        sc = torch.empty((1 << 20,), device=DEV)
+        cnt = torch.zeros((), dtype=torch.long, device=DEV)
+        add(f"global_topk_select N{n} M{n} k{k}",
+            lambda score=score, k=k, idx=idx, sc=sc: ext.global_topk_select(score, k, out_row=idx[0], out_col=idx[1], out_score=sc),
+            n * n, "Mcells/s")
+        add(f"global_topk_select_torchref N{n} M{n} k{k}", lambda score=score, k=k: score.view(-1).topk(k), n * n, "Mcells/s")
+        add(f"threshold_select N{n} M{n} thr3.0",
+            lambda score=score, idx=idx, sc=sc, cnt=cnt: ext.threshold_select(score, 3.0, out_row=idx[0], out_col=idx[1],
+                                                                              out_score=sc, num_out=cnt),
+            n * n, "Mcells/s")
+        add(f"threshold_select_torchref N{n} M{n} thr3.0", lambda score=score: torch.nonzero(score > 3.0, as_tuple=True),
+            n * n, "Mcells/s")
+    # ---- voxelisation (ops/voxelize.py) at the config-4 size, with 32 feature channels ---------------------------------
+    for (nc, n, vs, c) in ((16, 30000, 0.025, 32),):
+        pts = (torch.rand((nc * n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
+        fts = torch.randn((nc * n, c), generator=g).to(DEV)
+        lens = torch.full((nc,), n, dtype=torch.long).to(DEV)
+        vox = torch.empty((nc * n, 3), dtype=torch.long, device=DEV)
+        nodes, vf = torch.empty_like(pts), torch.empty_like(fts)
+        vl, num = torch.empty_like(lens), torch.zeros((), dtype=torch.long, device=DEV)
+        add(f"voxelize_pack B{nc} N{n} v{vs} C{c}",
+            lambda pts=pts, lens=lens, vox=vox, nodes=nodes, vl=vl, num=num, fts=fts, vf=vf, vs=vs:
+            ext.voxelize_pack(pts, lens, vox, nodes, vl, num, vs, feats=fts, voxel_feats=vf), nc * n, "Mpts/s")
     # ---- pack-mode row gathers (KPConv stage shapes: 16 x 30,000 points, 38 neighbours) ------------
     for (n, k, c) in ((480000, 38, 64), (120000, 36, 256)):
         feats = torch.randn((n, c), generator=g).to(DEV)

@@ -18,12 +18,12 @@ from .matching import (extract_correspondences_from_feats, extract_correspondenc
                        extract_correspondences_from_scores_threshold, extract_correspondences_from_scores_topk)
 from .superpoint_matching import SuperPointMatchingGlobalTopk, SuperPointMatchingMutualTopk
 from .mutual_topk_select import batch_mutual_topk_select, mutual_topk_select
-from .pack_gather import (global_avgpool_pack_mode, index_select, knn_interpolate_pack_mode,
+from .pack_gather import (global_avgpool_pack_mode, index_select, knn_interpolate, knn_interpolate_pack_mode,
                           local_maxpool_pack_mode, nearest_interpolate_pack_mode)
 from .pairwise_distance import pairwise_distance
 from .grid_subsample import grid_subsample_pack_mode
-from .point_cloud_partition import ball_query_partition, point_to_node_partition
-from .radius_search import radius_count_pack_mode, radius_search_pack_mode
+from .point_cloud_partition import ball_query_partition, get_point_to_node_indices, point_to_node_partition
+from .radius_search import naive_radius_search_pack_mode, radius_count_pack_mode, radius_search_pack_mode
 from .three_interpolate import three_interpolate
 from .three_nn import three_nn
 from .voxelize import voxelize, voxelize_pack_mode
@@ -34,7 +34,8 @@ __all__ = [
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats", "extract_correspondences_from_scores",
     "extract_correspondences_from_scores_threshold", "extract_correspondences_from_scores_topk",
-    "SuperPointMatchingGlobalTopk", "SuperPointMatchingMutualTopk", "voxelize", "voxelize_pack_mode",
+    "SuperPointMatchingGlobalTopk", "SuperPointMatchingMutualTopk", "voxelize", "voxelize_pack_mode", "knn_interpolate", "get_point_to_node_indices",
+    "naive_radius_search_pack_mode",
     "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
     "knn_interpolate_pack_mode", "sa_group", "edge_group", "kpconv_gather", "kpconv", "point_to_node_partition", "ball_query_partition",
 ]

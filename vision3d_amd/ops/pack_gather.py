@@ -189,3 +189,28 @@ def knn_interpolate_pack_mode(
         knn_feats = index_select(padded, table[:, :k_used].contiguous(), dim=0)
         return (knn_feats * weights.to(s_feats.dtype).unsqueeze(-1)).sum(dim=1)
     return _RowsWeightedSum.apply(s_feats, table, weights)
+
+
+def knn_interpolate(
+    q_points: Tensor,
+    s_points: Tensor,
+    s_feats: Tensor,
+    k: int = 3,
+    eps: float = 1e-10,
+    distance_limit: Optional[float] = None,
+) -> Tensor:
+    """Inverse-distance interpolation of ``s_feats`` (N, C) at ``q_points`` (M, 3) over the ``k`` nearest supports
+    (knn_interpolate.py:10-40).  The search is the native 3-D kNN (the reference: pykeops), the (M, k, C) gather and its
+    weighted sum are one fused kernel; gradients flow to ``s_feats`` through the ordered row scatter."""
+    from .knn import keops_knn
+
+    _require_cuda("knn_interpolate", q_points, s_points, s_feats)
+    knn_distances, knn_indices = keops_knn(q_points.detach(), s_points.detach(), k)  # :32
+    if distance_limit is not None:  # :33-35
+        knn_distances = knn_distances.masked_fill(torch.gt(knn_distances, distance_limit), 1e10)
+    weights = 1.0 / (knn_distances + eps)  # :36
+    weights = weights / weights.sum(dim=1, keepdim=True)  # :37
+    if s_feats.dtype != torch.float32 or s_feats.shape[1] % 4 != 0:
+        knn_feats = index_select(s_feats, knn_indices, dim=0)  # :38
+        return (knn_feats * weights.to(s_feats.dtype).unsqueeze(-1)).sum(dim=1)  # :39
+    return _RowsWeightedSum.apply(s_feats, knn_indices.contiguous(), weights.contiguous())

@@ -71,3 +71,10 @@ def ball_query_partition(
     if return_count:
         return node_knn_indices, node_knn_masks, node_masks, node_sizes
     return node_knn_indices, node_knn_masks, node_masks
+
+
+def get_point_to_node_indices(points: Tensor, nodes: Tensor, return_counts: bool = False):
+    """Deprecated spelling kept by the reference (point_cloud_partition.py:13-37): nearest node of every point and,
+    optionally, the node sizes -- the first outputs of ``point_to_node_partition``."""
+    out = point_to_node_partition(points, nodes, return_count=return_counts, gather_points=False)
+    return (out[0], out[1]) if return_counts else out[0]

@@ -45,3 +45,9 @@ def radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf
     ext.radius_count(batch_q_points.contiguous(), batch_s_points.contiguous(), counts, radius)
     radius_counts, _ = batch_to_pack(counts, batch_q_masks)
     return radius_counts
+
+
+def naive_radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit):
+    """The reference's per-cloud loop (radius_search.py:8-41) computes the same table as the fast version; here both
+    names reach the same native kernel."""
+    return radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit)
