@@ -52,12 +52,84 @@ __device__ __forceinline__ void grp_channel(const GroupArgs& a, int b, int oc, c
   }
 }
 
+// Source row / centre row of output channel oc, as plain values: the three base pointers are direct kernel arguments
+// (so the loads are global_load, not flat_load) and nothing is selected through memory.  An earlier version kept them in
+// the by-value GroupArgs and chose the row inside lambdas: the compiler passed the chosen pointer through a scratch slot,
+// and the scratch_load's s_waitcnt vmcnt(0) at the top of every channel drained all stores of the previous channel.
+struct GrpSel {
+  const float* row;   // valid iff has_row
+  const float* crow;  // valid iff has_ctr
+  bool has_row, has_ctr;
+};
+template <bool CTR>
+__device__ __forceinline__ GrpSel grp_select(const float* src0, const float* src1, const float* ctr, const GroupArgs& a,
+                                             int b, int oc) {
+  GrpSel s;
+  if (!CTR) {
+    s.row = src0 + ((int64_t)b * a.C0 + oc) * a.N;
+    s.crow = src0;
+    s.has_row = true;
+    s.has_ctr = false;
+    return s;
+  }
+  const int cc = a.share_ctr ? a.C1 : a.Cb + a.C1;
+  const bool plain = oc < a.C0, bcast = !plain && oc < a.C0 + a.Cb;
+  const int c = plain ? oc : (bcast ? oc - a.C0 : oc - a.C0 - a.Cb);
+  const int64_t r0 = ((int64_t)b * a.C0 + c) * a.N, r1 = ((int64_t)b * a.C1 + c) * a.N;
+  // broadcast channels have no source row: they stage a valid dummy row (never read) so that the row loads are
+  // unconditional -- conditional loads make the compiler wait for ALL outstanding stores before it reuses the registers
+  const float* dummy = a.C1 ? src1 + (int64_t)b * a.C1 * a.N : src0 + (int64_t)b * a.C0 * a.N;
+  s.row = plain ? src0 + r0 : (bcast ? dummy : src1 + r1);
+  s.crow = ctr + ((int64_t)b * cc + (plain ? 0 : ((bcast || a.share_ctr) ? c : a.Cb + c))) * a.M;  // plain: dummy
+  s.has_row = !bcast;
+  s.has_ctr = !plain;
+  return s;
+}
+
+// (a native vector, not HIP's uint4 struct: struct copies between address spaces become memcpy calls that keep the staging
+// array in scratch memory)
+typedef unsigned grp_u32x4 __attribute__((ext_vector_type(4)));
+// Staging of one channel: loads into registers (addresses clamped, not predicated), later written to an LDS buffer.
+template <bool CTR, int NSTAGE>
+__device__ __forceinline__ void grp_issue(const GrpSel& sel, grp_u32x4 (&stg)[NSTAGE], float (&cst)[kGrpCtrVals], int tid,
+                                          int nvec, int m_first, int m_count) {
+  const grp_u32x4* row4 = reinterpret_cast<const grp_u32x4*>(sel.row);
+#pragma unroll
+  for (int i = 0; i < NSTAGE; ++i) stg[i] = row4[min(i * kGrpThreads + tid, nvec - 1)];
+  if (CTR) {
+#pragma unroll
+    for (int i = 0; i < kGrpCtrVals; ++i) cst[i] = sel.crow[m_first + min(i * kGrpThreads + tid, m_count - 1)];
+  }
+}
+template <bool CTR, int NSTAGE>
+__device__ __forceinline__ void grp_commit(const grp_u32x4 (&stg)[NSTAGE], const float (&cst)[kGrpCtrVals], float* rows_buf,
+                                           float* ctrs_buf, int tid, int nvec, int m_count) {
+  grp_u32x4* dr = reinterpret_cast<grp_u32x4*>(rows_buf);
+#pragma unroll
+  for (int i = 0; i < NSTAGE; ++i) {
+    const int v = i * kGrpThreads + tid;
+    if (v < nvec) dr[v] = stg[i];
+  }
+  if (CTR) {
+#pragma unroll
+    for (int i = 0; i < kGrpCtrVals; ++i) {
+      const int v = i * kGrpThreads + tid;
+      if (v < m_count) ctrs_buf[v] = cst[i];
+    }
+  }
+}
+
 // KV: K % 4 == 0, so the four positions of a vector share one query.
 // CTR: the launch has broadcast / offset channels (false = plain gather: no query bookkeeping at all).
 template <bool KV, bool CTR, int NSTAGE>
-__global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs a, const int64_t* __restrict__ idx,
-                                                                      float* __restrict__ out, int CT, int row_elems,
-                                                                      int ctr_elems, GridMap gm) {
+__global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(const float* src0, const float* src1,
+                                                                      const float* ctr, GroupArgs a,
+                                                                      const int64_t* __restrict__ idx, float* out, int CT,
+                                                                      int row_elems, int ctr_elems, GridMap gm) {
+  // src0 / src1 / ctr / out are deliberately NOT __restrict__: with the no-alias promise the compiler sinks the staging
+  // loads of the next row below this channel's stores, next to the LDS writes that consume them, and each load then
+  // waits with vmcnt(0) -- i.e. for every store in flight.  As possibly-aliasing accesses they stay where they are
+  // written: above the stores.
   extern __shared__ __align__(16) float grp_smem[];
   float* rows = grp_smem;                         // 2 x row_elems: source row (+ zero slot at N)
   float* ctrs = grp_smem + 2 * row_elems;         // 2 x ctr_elems: centre values of this tile's queries
@@ -70,6 +142,7 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs 
   const int64_t tile0 = (int64_t)bx * kGrpTile;
   const int m_first = (int)(tile0 / a.K);
   const int m_count = (int)(min(L, tile0 + kGrpTile) - 1) / a.K - m_first + 1;
+  const bool full = tile0 + kGrpTile <= L;  // every vector of every thread is inside the row: no per-store test
 
   int my[kGrpR][kGrpVec];
   int mq[kGrpR][KV ? 1 : kGrpVec];
@@ -98,77 +171,80 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(GroupArgs 
     rows[row_elems + a.N] = 0.f;
   }
   // register staging: the next channel's source row (16-byte pieces) and centre values are requested before this
-  // channel's gathers and stores and written to the other LDS buffer after them
+  // channel's gathers and stores and written to the other LDS buffer after them; the wait before that write counts the
+  // stores issued in between, so they stay in flight
   const int nvec = a.N >> 2;
-  uint4 stg[NSTAGE];
+  grp_u32x4 stg[NSTAGE];
   float cst[kGrpCtrVals];
-  bool st_row = false, st_ctr = false;
-  auto issue = [&](int oc) {
-    const float *row, *crow;
-    grp_channel(a, b, oc, row, crow);
-    st_row = row != nullptr;
-    st_ctr = CTR && crow != nullptr;
-    const uint4* row4 = reinterpret_cast<const uint4*>(row);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  GrpSel nxt = grp_select<CTR>(src0, src1, ctr, a, b, c0);
+  grp_issue<CTR, NSTAGE>(nxt, stg, cst, tid, nvec, m_first, m_count);
+  grp_commit<CTR, NSTAGE>(stg, cst, rows, ctrs, tid, nvec, m_count);
+  // Two loops, chosen once: whole tiles (every path through the body issues exactly eight stores between the staging
+  // loads and the LDS writes that consume them, so the compiler's wait there is a COUNTED vmcnt and the stores stay in
+  // flight) and the last, partial tile of a row (per-store tests; its waits drain the queue, it is one tile per row).
+  if (full) {
+    for (int oc = c0; oc < c1; ++oc) {
+      __syncthreads();
+      const int which = (oc - c0) & 1;
+      const float* cur = rows + which * row_elems;
+      const float* cc = ctrs + which * ctr_elems;
+      const bool has_row = !CTR || nxt.has_row, has_ctr = CTR && nxt.has_ctr;  // of channel oc (selected last iteration)
+      // the next channel's row is requested now and written to the other buffer after this channel's stores; the last
+      // channel re-stages itself (one redundant L2 read per workgroup) so that nothing in the loop is conditional
+      nxt = grp_select<CTR>(src0, src1, ctr, a, b, min(oc + 1, c1 - 1));
+      grp_issue<CTR, NSTAGE>(nxt, stg, cst, tid, nvec, m_first, m_count);
+      float* orow = out + ((int64_t)b * Cout + oc) * L + tile0 + (int64_t)tid * kGrpVec;
+      f32x4 pk[kGrpR];
+      if (!CTR || (has_row && !has_ctr)) {  // plain gather: 32 LDS reads, then 8 stores, no tests
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-      const int v = i * kGrpThreads + tid;
-      stg[i] = (st_row && v < nvec) ? row4[v] : make_uint4(0, 0, 0, 0);
-    }
-    if (CTR) {
+        for (int r = 0; r < kGrpR; ++r) pk[r] = f32x4{cur[my[r][0]], cur[my[r][1]], cur[my[r][2]], cur[my[r][3]]};
+      } else if (has_row) {  // gather minus centre
 #pragma unroll
-      for (int i = 0; i < kGrpCtrVals; ++i) {
-        const int v = i * kGrpThreads + tid;
-        cst[i] = (st_ctr && v < m_count) ? crow[m_first + v] : 0.f;
-      }
-    }
-  };
-  auto commit = [&](int which) {
-    uint4* dr = reinterpret_cast<uint4*>(rows + which * row_elems);
-    float* dc = ctrs + which * ctr_elems;
-    if (st_row) {
+        for (int r = 0; r < kGrpR; ++r) {
 #pragma unroll
-      for (int i = 0; i < NSTAGE; ++i) {
-        const int v = i * kGrpThreads + tid;
-        if (v < nvec) dr[v] = stg[i];
-      }
-    }
-    if (CTR && st_ctr) {
-#pragma unroll
-      for (int i = 0; i < kGrpCtrVals; ++i) {
-        const int v = i * kGrpThreads + tid;
-        if (v < m_count) dc[v] = cst[i];
-      }
-    }
-  };
-  issue(c0);
-  commit(0);
-  for (int oc = c0; oc < c1; ++oc) {
-    __syncthreads();
-    const int which = (oc - c0) & 1;
-    const float* cur = rows + which * row_elems;
-    const float* cc = ctrs + which * ctr_elems;
-    const bool have_next = oc + 1 < c1;
-    if (have_next) issue(oc + 1);
-    const bool has_row = oc < a.C0 || oc >= a.C0 + a.Cb;
-    const bool has_ctr = CTR && oc >= a.C0;
-    float* orow = out + ((int64_t)b * Cout + oc) * L;
-#pragma unroll
-    for (int r = 0; r < kGrpR; ++r) {
-      const int64_t p0 = tile0 + ((int64_t)r * kGrpThreads + tid) * kGrpVec;
-      if (p0 < L) {
-        float v[kGrpVec];
-#pragma unroll
-        for (int e = 0; e < kGrpVec; ++e) {
-          const float g = has_row ? cur[my[r][e]] : 0.f;
-          const float q = (CTR && has_ctr) ? cc[mq[r][KV ? 0 : e]] : 0.f;
-          v[e] = has_row ? (has_ctr ? g - q : g) : q;
+          for (int e = 0; e < kGrpVec; ++e) pk[r][e] = cur[my[r][e]] - cc[mq[r][KV ? 0 : e]];
         }
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 pk = {v[0], v[1], v[2], v[3]};
-        __builtin_nontemporal_store(pk, reinterpret_cast<f32x4*>(orow + p0));
+      } else {  // broadcast centre
+#pragma unroll
+        for (int r = 0; r < kGrpR; ++r) {
+#pragma unroll
+          for (int e = 0; e < kGrpVec; ++e) pk[r][e] = cc[mq[r][KV ? 0 : e]];
+        }
       }
+#pragma unroll
+      for (int r = 0; r < kGrpR; ++r)
+        __builtin_nontemporal_store(pk[r], reinterpret_cast<f32x4*>(orow + (int64_t)r * kGrpThreads * kGrpVec));
+      grp_commit<CTR, NSTAGE>(stg, cst, rows + (which ^ 1) * row_elems, ctrs + (which ^ 1) * ctr_elems, tid, nvec,
+                              m_count);
     }
-    if (have_next) commit(which ^ 1);  // that buffer was last read before this iteration's barrier
+  } else {
+    for (int oc = c0; oc < c1; ++oc) {
+      __syncthreads();
+      const int which = (oc - c0) & 1;
+      const float* cur = rows + which * row_elems;
+      const float* cc = ctrs + which * ctr_elems;
+      const bool has_row = !CTR || nxt.has_row, has_ctr = CTR && nxt.has_ctr;
+      nxt = grp_select<CTR>(src0, src1, ctr, a, b, min(oc + 1, c1 - 1));
+      grp_issue<CTR, NSTAGE>(nxt, stg, cst, tid, nvec, m_first, m_count);
+      float* orow = out + ((int64_t)b * Cout + oc) * L + tile0 + (int64_t)tid * kGrpVec;
+#pragma unroll
+      for (int r = 0; r < kGrpR; ++r) {
+        const int64_t p0 = tile0 + ((int64_t)r * kGrpThreads + tid) * kGrpVec;
+        if (p0 < L) {
+          f32x4 pk;
+#pragma unroll
+          for (int e = 0; e < kGrpVec; ++e) {
+            const float g = has_row ? cur[my[r][e]] : 0.f;
+            const float q = has_ctr ? cc[mq[r][KV ? 0 : e]] : 0.f;
+            pk[e] = has_row ? (has_ctr ? g - q : g) : q;
+          }
+          __builtin_nontemporal_store(pk, reinterpret_cast<f32x4*>(orow + (int64_t)r * kGrpThreads * kGrpVec));
+        }
+      }
+      grp_commit<CTR, NSTAGE>(stg, cst, rows + (which ^ 1) * row_elems, ctrs + (which ^ 1) * ctr_elems, tid, nvec,
+                              m_count);
+    }
   }
 }
 
@@ -195,7 +271,7 @@ static bool group_lds_ok(const GroupArgs& a, const float* out) {
   const size_t ctr_elems = align_up((size_t)(kGrpTile / std::max(a.K, 1) + 2) * 4, 16) / 4;
   const size_t lds = sizeof(float) * 2 * (row_elems + ctr_elems);
   const uintptr_t srcs = (uintptr_t)a.src0 | (uintptr_t)a.src1;
-  return a.N % 4 == 0 && a.N <= kGrpRowVecs * kGrpThreads * 4 && (srcs & 15) == 0 &&
+  return a.N % 4 == 0 && a.N >= 4 && a.C0 + a.C1 > 0 && a.N <= kGrpRowVecs * kGrpThreads * 4 && (srcs & 15) == 0 &&
          kGrpTile / std::max(a.K, 1) + 2 <= kGrpCtrVals * kGrpThreads && lds <= 65536 && L % kGrpVec == 0 &&
          ((uintptr_t)out & 15) == 0 && L >= kGrpTile / 4;
 }
@@ -226,8 +302,8 @@ static int launch_group_fused(const char* what, const GroupArgs& a, const int64_
   const GridMap gm = make_grid_map(xblocks, yblocks, B);
   const dim3 grid((unsigned)(xblocks * yblocks * B)), block(kGrpThreads);
 #define V3D_GRP_LAUNCH_NS(KV, CTR, NS)                                                                                \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(group_fused_lds_kernel<KV, CTR, NS>), grid, block, lds, stream, a, idx, out, CT, \
-                     row_elems, ctr_elems, gm)
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(group_fused_lds_kernel<KV, CTR, NS>), grid, block, lds, stream, a.src0, a.src1, \
+                     a.ctr, a, idx, out, CT, row_elems, ctr_elems, gm)
 #define V3D_GRP_LAUNCH(KV, CTR)                            \
   do {                                                     \
     if (per_thread <= 1) V3D_GRP_LAUNCH_NS(KV, CTR, 1);    \
