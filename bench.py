@@ -49,8 +49,10 @@ def make_inputs(seed, device):
 class Step:
     """Pre-allocated buffers + the operator sequence; `timers` collects (name, start_event, end_event)."""
 
-    def __init__(self, inp, device):
+    def __init__(self, inp, device, fused_msg=False):
         from vision3d_amd import ext
+
+        self.fused_msg = fused_msg
 
         self.ext = ext
         self.inp = inp
@@ -85,9 +87,15 @@ class Step:
         self._timed("fps", lambda: ext.furthest_point_sample(self.pts, self.fps_dist, self.fps_idx, M))
         self._timed("gather_centroids", lambda: ext.gather_forward(self.pts_cf, self.fps_idx, self.q_cf))
         q = self.q_cf.transpose(1, 2).contiguous()  # (B,M,3)
+        if self.fused_msg:  # one pass over the pairs for the three MSG scales (not the reference's call pattern)
+            for t in self.ball_idx:
+                t.zero_()
+            self._timed("ball_query_msg3", lambda: ext.ball_query_multi(q, self.pts, self.ball_idx,
+                                                                        [r for r, _ in SCALES], [k for _, k in SCALES]))
         for i, (r, k) in enumerate(SCALES):
-            self.ball_idx[i].zero_()
-            self._timed(f"ball_query_k{k}", lambda: ext.ball_query(q, self.pts, self.ball_idx[i], r, k))
+            if not self.fused_msg:
+                self.ball_idx[i].zero_()
+                self._timed(f"ball_query_k{k}", lambda: ext.ball_query(q, self.pts, self.ball_idx[i], r, k))
             self._timed(f"group_gather_xyz_k{k}",
                         lambda: ext.group_gather_forward(self.pts_cf, self.ball_idx[i], self.g_xyz[i]))
             self._timed(f"group_gather_feat_k{k}",
@@ -162,6 +170,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight (one HIP stream each)")
+    ap.add_argument("--fused-msg", action="store_true",
+                    help="one ext.ball_query_multi launch for the three MSG scales instead of the reference's three "
+                         "ball_query calls (same outputs; off by default: the default step is the reference's call pattern)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,7 +195,7 @@ def main():
     steps = []
     for s in streams:
         with torch.cuda.stream(s):
-            steps.append(Step(inp, device))
+            steps.append(Step(inp, device, fused_msg=args.fused_msg))
     torch.cuda.synchronize()
 
     def run_steps(n):
@@ -242,7 +253,8 @@ def main():
             "config": {"workload": "pointnet2_msg_fp_s3dis", "B_per_gpu": B, "N": N, "M": M,
                        "scales": [list(s) for s in SCALES], "C_group": C_FEAT, "C_interp": C_INTERP,
                        "sharding": f"batch x{world} (independent clouds, no data-path collective)",
-                       "batches_in_flight": nstream},
+                       "batches_in_flight": nstream,
+                       "ball_query": "one launch for the 3 MSG scales" if args.fused_msg else "one launch per scale"},
             "fps_points_per_sec": B * N * world / (per_op_ms["fps"] * 1e-3),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -62,6 +62,14 @@ int v3d_ball_query_f32(const float* q, const float* s, int64_t* indices, int B, 
 int v3d_ball_query_f64(const double* q, const double* s, int64_t* indices, int B, int M, int N,
                        float max_radius, int k, int device, void* stream);
 
+/* Multi-scale form for PointNet++ MSG grouping (models/pointnet2/modules.py:47-57 calls ball_query once per
+ * (radius, k) on the same queries and supports): num_scales (1..4) outputs in ONE pass over the pairs.  indices /
+ * max_radii / num_samples are HOST arrays of num_scales entries; indices[i] is the device tensor (B,M,num_samples[i]) of
+ * scale i, arriving zero-filled like above.  Every output is bit-identical to v3d_ball_query_f32 with that scale's
+ * arguments. */
+int v3d_ball_query_multi_f32(const float* q, const float* s, int64_t* const* indices, const float* max_radii,
+                             const int* num_samples, int num_scales, int B, int M, int N, int device, void* stream);
+
 /* ---- knn_points (3-D, heap based) -------------------------------------------------------------------
  * replaces vision3d::knn_points (csrc/cuda/knn_points/knn_points.h; kernel knn_points_cuda.cuh:41-93),
  * also reachable as `knn` through the host shim (ops/knn_points.py:36 calls ext.knn).

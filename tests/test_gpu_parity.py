@@ -120,6 +120,41 @@ def test_ball_query(ext, oracle_mod, dtype):
             assert np.array_equal(N_(idx), want), (name, k, r)
 
 
+def test_ball_query_multi_equals_single_scale_queries(ext, oracle_mod):
+    """The multi-scale pass (PointNet++ MSG) against the oracle scale by scale: sorted and unsorted radii, a scale that
+    never fills (full scan) next to one that fills at once, lattice / duplicate ties, empty balls, ragged M and N."""
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(21)
+    for name, pts in clouds(rng).items():
+        s = pts.astype(np.float32)
+        q = np.concatenate([s[:, : min(70, s.shape[1])], s[:, :3] + 50.0], axis=1)
+        for ks, rs in (((16, 32, 128), (0.1, 0.2, 0.4)), ((8, 1), (0.3, 0.05)), ((130, 4, 32, 70), (10.0, 0.01, 0.2, 0.6)),
+                       ((5,), (0.25,))):
+            got = ops.ball_query_multi(T(q), T(s), ks, rs)
+            assert len(got) == len(ks)
+            for k, r, g in zip(ks, rs, got):
+                assert np.array_equal(N_(g), oracle_mod.ball_query(q, s, k, r)), (name, k, r)
+    # transposed layout and the single-call form agree
+    s = rng.random((2, 300, 3), dtype=np.float32)
+    a = ops.ball_query_multi(T(s).transpose(1, 2), T(s).transpose(1, 2), (8, 16), (0.1, 0.2), transposed=True)
+    assert torch.equal(a[0], ops.ball_query(T(s), T(s), 8, 0.1)) and torch.equal(a[1], ops.ball_query(T(s), T(s), 16, 0.2))
+    with pytest.raises(RuntimeError, match="scales"):
+        ext.ball_query_multi(T(s), T(s), [], [], [])
+
+
+def test_ball_query_multi_full_size_c2(ext):
+    """BASELINE config 2 (B 32, N 4096, M 1024, the three MSG scales): identical to three single-scale launches."""
+    from vision3d_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(2)
+    s = torch.rand((32, 4096, 3), device=DEV, generator=g)
+    q = s[:, ::4].contiguous()
+    got = ops.ball_query_multi(q, s, (16, 32, 128), (0.1, 0.2, 0.4))
+    for k, r, t in zip((16, 32, 128), (0.1, 0.2, 0.4), got):
+        assert torch.equal(t, ops.ball_query(q, s, k, r)), (k, r)
+
+
 def test_ball_query_leaves_unmatched_rows_untouched(ext):
     s = torch.zeros((1, 10, 3), device=DEV)
     q = torch.full((1, 4, 3), 100.0, device=DEV)

@@ -29,6 +29,9 @@ SIGNATURES = {
     "v3d_fps_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_ball_query_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32, _c_int] + _TAIL),
     "v3d_ball_query_f64": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32, _c_int] + _TAIL),
+    "v3d_ball_query_multi_f32": (
+        _c_int, [_c_ptr, _c_ptr, ctypes.POINTER(_c_ptr), ctypes.POINTER(_c_f32), ctypes.POINTER(_c_int), _c_int, _c_int,
+                 _c_int, _c_int] + _TAIL),
     "v3d_knn_points_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_knn_points_f64": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_three_nn_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int] + _TAIL),

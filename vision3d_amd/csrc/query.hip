@@ -214,6 +214,114 @@ static int ball_query(const T* q, const T* s, int64_t* out, int B, int M, int N,
   return launch_status(what);
 }
 
+// Multi-scale grouping (PointNet++ MSG, models/pointnet2/modules.py:47-57, calls ball_query once per (radius, k) on the
+// same queries and supports): one pass evaluates every pair ONCE and tests it against all S radii; each scale keeps its
+// own counters, first hit and output tensor, so every output equals the single-scale kernel's bit for bit.  A query
+// leaves the scan when all of its scales are full.
+constexpr int kBallMaxScales = 4;
+struct BallScales {
+  int64_t* out[kBallMaxScales];
+  float r2[kBallMaxScales];
+  int k[kBallMaxScales];
+};
+
+template <int S, int G, int TS>
+__global__ __launch_bounds__(kQueryThreads) void ball_query_multi_kernel(const float* __restrict__ q,
+                                                                         const float* __restrict__ s, BallScales sc, int M,
+                                                                         int N) {
+  __shared__ __align__(16) float tile[TS * 3];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q_first = (blockIdx.x * kWavesPerBlock + wave) * G;
+  const float* s_cloud = s + (int64_t)b * N * 3;
+
+  float qx[G], qy[G], qz[G];
+  int cnt[G][S], first[G][S];
+  float lim[G][S];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int qi = q_first + g;
+    const bool live = qi < M;
+    const float* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
+    qx[g] = qp[0];
+    qy[g] = qp[1];
+    qz[g] = qp[2];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      cnt[g][i] = live ? 0 : sc.k[i];  // dead slots count as full
+      first[g][i] = -1;
+    }
+  }
+
+  for (int t0 = 0; t0 < N; t0 += TS) {
+    const int tcount = min(TS, N - t0);
+    __syncthreads();
+    stage_supports_aos(s_cloud, t0, tcount, tile);
+    {
+      const int padded = (tcount + 63) & ~63;
+      for (int i = tcount * 3 + (int)threadIdx.x; i < padded * 3; i += kQueryThreads) tile[i] = INFINITY;
+    }
+    __syncthreads();
+    bool all_full = true;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        all_full = all_full && (cnt[g][i] >= sc.k[i]);
+        lim[g][i] = cnt[g][i] < sc.k[i] ? sc.r2[i] : -1.0f;  // a full (or dead) list can never hit again
+      }
+    }
+    if (all_full) continue;  // wave-uniform; keep taking part in the barriers
+    for (int c0 = 0; c0 < tcount; c0 += 64) {
+      const int j = c0 + lane;
+      const float sx = tile[j * 3 + 0], sy = tile[j * 3 + 1], sz = tile[j * 3 + 2];
+      unsigned long long m[G][S];
+      unsigned long long any = 0ull;
+#pragma unroll
+      for (int g = 0; g < G; g += 2) {
+        float d0, d1;
+        sq_dist_pair(qx[g], qy[g], qz[g], qx[g + 1], qy[g + 1], qz[g + 1], sx, sy, sz, d0, d1);
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          m[g][i] = __ballot(d0 < lim[g][i]);  // strict, ball_query_cuda.cuh:43
+          m[g + 1][i] = __ballot(d1 < lim[g + 1][i]);
+          any |= m[g][i] | m[g + 1][i];
+        }
+      }
+      if (any == 0ull) continue;
+      bool open = false;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          const unsigned long long mm = m[g][i];
+          if (mm) {  // wave-uniform
+            const bool hit = (mm >> lane) & 1ull;
+            const int slot = cnt[g][i] + __builtin_popcountll(mm & ((1ull << lane) - 1ull));
+            if (hit && slot < sc.k[i]) sc.out[i][((int64_t)b * M + q_first + g) * sc.k[i] + slot] = (int64_t)(t0 + j);
+            if (first[g][i] < 0) first[g][i] = t0 + c0 + (__builtin_ffsll((long long)mm) - 1);
+            cnt[g][i] += __builtin_popcountll(mm);
+            if (cnt[g][i] >= sc.k[i]) lim[g][i] = -1.0f;
+          }
+          open = open || (cnt[g][i] < sc.k[i]);
+        }
+      }
+      if (!open) break;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      if (q_first + g < M && cnt[g][i] > 0 && cnt[g][i] < sc.k[i]) {  // ball_query_cuda.cuh:44-48
+        int64_t* row = sc.out[i] + ((int64_t)b * M + q_first + g) * sc.k[i];
+        for (int slot = cnt[g][i] + lane; slot < sc.k[i]; slot += 64) row[slot] = (int64_t)first[g][i];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // three_nn
 // ------------------------------------------------------------------------------------------------------
@@ -660,6 +768,41 @@ extern "C" {
 int v3d_ball_query_f32(const float* q, const float* s, int64_t* indices, int B, int M, int N, float max_radius, int k,
                        int device, void* stream) {
   return v3d::ball_query<float>(q, s, indices, B, M, N, max_radius, k, device, stream);
+}
+int v3d_ball_query_multi_f32(const float* q, const float* s, int64_t* const* indices, const float* max_radii,
+                             const int* num_samples, int num_scales, int B, int M, int N, int device, void* stream_) {
+  using namespace v3d;
+  const char* what = "ball_query_multi";
+  V3D_REQUIRE(B >= 0 && M >= 0 && N >= 0, what, "negative dimension");
+  V3D_REQUIRE(num_scales >= 1 && num_scales <= kBallMaxScales, what, "1 to 4 scales per call");
+  V3D_REQUIRE(indices && max_radii && num_samples, what, "null pointer");
+  BallScales sc{};
+  int S = 0;
+  for (int i = 0; i < num_scales; ++i) {
+    V3D_REQUIRE(num_samples[i] >= 0, what, "negative dimension");
+    if (num_samples[i] == 0) continue;  // nothing to write for this scale
+    V3D_REQUIRE(indices[i] || B == 0 || M == 0, what, "null pointer");
+    sc.out[S] = indices[i];
+    sc.k[S] = num_samples[i];
+    sc.r2[S] = max_radii[i] * max_radii[i];  // float(r) * float(r), ball_query_cuda.cuh:28
+    ++S;
+  }
+  if (B == 0 || M == 0 || N == 0 || S == 0) return 0;
+  V3D_REQUIRE(q && s, what, "null pointer");
+  if (B > kMaxGridYZ) {
+    set_last_error("%s: B <= 65535 required", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  constexpr int G = 4, TS = 2048;
+  const dim3 grid((unsigned)ceil_div(M, kWavesPerBlock * G), (unsigned)B), block(kQueryThreads);
+  if (S == 1) hipLaunchKernelGGL((ball_query_kernel<float, G, TS>), grid, block, 0, stream, q, s, sc.out[0], M, N, sc.k[0], sc.r2[0]);
+  else if (S == 2) hipLaunchKernelGGL((ball_query_multi_kernel<2, G, TS>), grid, block, 0, stream, q, s, sc, M, N);
+  else if (S == 3) hipLaunchKernelGGL((ball_query_multi_kernel<3, G, TS>), grid, block, 0, stream, q, s, sc, M, N);
+  else hipLaunchKernelGGL((ball_query_multi_kernel<4, G, TS>), grid, block, 0, stream, q, s, sc, M, N);
+  return launch_status(what);
 }
 int v3d_ball_query_f64(const double* q, const double* s, int64_t* indices, int B, int M, int N, float max_radius,
                        int k, int device, void* stream) {

@@ -15,6 +15,7 @@ from . import _lib
 
 __all__ = [
     "ball_query",
+    "ball_query_multi",
     "furthest_point_sample",
     "gather_forward",
     "gather_backward",
@@ -108,6 +109,32 @@ def _workspace(nbytes, like):
 
 
 # --------------------------------------------------------------------------------------------------------
+def ball_query_multi(q_points, s_points, indices_list, max_radii, num_samples_list):
+    """Multi-scale ball query (PointNet++ MSG): up to four (radius, k) scales over the same clouds in one pass; every
+    ``indices_list[i]`` (B, M, num_samples_list[i]) arrives zero-filled and leaves equal to ``ball_query`` of that scale."""
+    import ctypes
+
+    n = len(indices_list)
+    if not (1 <= n <= 4) or len(max_radii) != n or len(num_samples_list) != n:
+        raise RuntimeError("ball_query_multi: 1 to 4 scales, one radius and one sample count per output")
+    _check_cuda_contiguous(q_points, "q_points")
+    _check_cuda_contiguous(s_points, "s_points")
+    _check_float(q_points, "q_points")
+    _check_float(s_points, "s_points")
+    B, M, N = q_points.size(0), q_points.size(1), s_points.size(1)
+    for t, k in zip(indices_list, num_samples_list):
+        _check_cuda_contiguous(t, "indices")
+        _check_long(t, "indices")
+        if tuple(t.shape) != (B, M, int(k)):
+            raise RuntimeError(f"ball_query_multi: indices must have shape {(B, M, int(k))}")
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in indices_list])
+    radii = (ctypes.c_float * n)(*[float(r) for r in max_radii])
+    ks = (ctypes.c_int * n)(*[int(k) for k in num_samples_list])
+    dev, stream = _where(q_points)
+    _lib.check(_lib.lib().v3d_ball_query_multi_f32(q_points.data_ptr(), s_points.data_ptr(), ptrs, radii, ks, n, B, M, N,
+                                                   dev, stream), "ball_query_multi")
+
+
 def ball_query(q_points, s_points, indices, max_radius, num_samples):
     _check_cuda_contiguous(q_points, "q_points")
     _check_cuda_contiguous(s_points, "s_points")

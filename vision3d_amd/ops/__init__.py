@@ -5,7 +5,7 @@ Same names, signatures, return values and error behaviour as the reference wrapp
 ``vision3d_amd.ext`` (hand-written gfx950 kernels behind a C ABI).  ``vision3d_amd.install()`` registers this
 package as ``vision3d.ops`` / ``vision3d.ext`` so unchanged model code imports it.
 """
-from .ball_query import ball_query
+from .ball_query import ball_query, ball_query_multi
 from .conversion import batch_to_pack, batch_to_pack_with_lengths, pack_to_batch
 from .furthest_point_sample import furthest_point_sample
 from .fused_group import edge_group, sa_group
@@ -29,7 +29,7 @@ from .three_nn import three_nn
 from .voxelize import voxelize, voxelize_pack_mode
 
 __all__ = [
-    "ball_query", "batch_to_pack", "batch_to_pack_with_lengths", "pack_to_batch", "furthest_point_sample", "gather",
+    "ball_query", "ball_query_multi", "batch_to_pack", "batch_to_pack_with_lengths", "pack_to_batch", "furthest_point_sample", "gather",
     "group_gather", "knn", "knn_pack_mode", "knn_points", "pairwise_distance", "radius_count_pack_mode",
     "grid_subsample_pack_mode", "radius_search_pack_mode", "three_interpolate", "three_nn",
     "mutual_topk_select", "batch_mutual_topk_select", "extract_correspondences_from_feats", "extract_correspondences_from_scores",
