@@ -70,10 +70,32 @@ __device__ __forceinline__ void load_neighbours(const int64_t* __restrict__ idx_
 // for the whole channel tile; the (b,c) source row (S+1 elements, slot S = 0 for out-of-range indices) is double
 // buffered in LDS with the next row's 16-byte loads in flight while the current row is interpolated and stored.
 // NSTAGE = 16-byte vectors per thread and row (0: element-wise staging for rows that are not 16-byte tileable).
+typedef unsigned interp_u32x4 __attribute__((ext_vector_type(4)));
+
+// One channel of one thread's targets: 3 LDS gathers, 3 products, 2 adds per target (reference order, no contraction).
+template <typename T, int VEC, int R>
+__device__ __forceinline__ void interp_channel(const T* cur, const int (&id)[R][VEC][3], const T (&wt)[R][VEC][3],
+                                               TPack<T, VEC> (&pk)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const T p0 = cur[id[r][e][0]] * wt[r][e][0];
+      const T p1 = cur[id[r][e][1]] * wt[r][e][1];
+      const T p2 = cur[id[r][e][2]] * wt[r][e][2];
+      pk[r].v[e] = (p0 + p1) + p2;
+    }
+  }
+}
+
+// Codegen notes (same as group.hip's kernel): `src` / `out` are not __restrict__ (the no-alias promise lets the compiler
+// sink the staging load below the stores, where it waits with vmcnt(0) = for every store in flight); the staging
+// registers are a native vector type; the staging load is clamped, not predicated, and the last channel re-stages
+// itself, so whole tiles run a loop without conditionals in which the wait before the LDS write is a counted vmcnt.
 template <typename T, int VEC, int R, int NSTAGE, bool VEC_STORE>
 __global__ __launch_bounds__(kInterpThreads) void three_interp_fwd_lds_kernel(
-    const T* __restrict__ src, const int64_t* __restrict__ idx, const T* __restrict__ w, T* __restrict__ out, int C,
-    int S, int Q, int CT, int buf_elems, GridMap gm) {
+    const T* src, const int64_t* __restrict__ idx, const T* __restrict__ w, T* out, int C, int S, int Q, int CT,
+    int buf_elems, GridMap gm) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x;
@@ -95,18 +117,41 @@ __global__ __launch_bounds__(kInterpThreads) void three_interp_fwd_lds_kernel(
     smem[buf_elems + S] = T(0);
   }
   const int nvec = (int)(((size_t)S * sizeof(T)) / 16);
-  uint4 stg[NSTAGE > 0 ? NSTAGE : 1];
+  interp_u32x4 stg[NSTAGE > 0 ? NSTAGE : 1];
   {
     const T* row = src + ((int64_t)b * C + c0) * S;
     if (NSTAGE > 0) {
 #pragma unroll
       for (int i = 0; i < NSTAGE; ++i) {
         const int v = i * kInterpThreads + tid;
-        if (v < nvec) reinterpret_cast<uint4*>(smem)[v] = reinterpret_cast<const uint4*>(row)[v];
+        if (v < nvec) reinterpret_cast<interp_u32x4*>(smem)[v] = reinterpret_cast<const interp_u32x4*>(row)[v];
       }
     } else {
       for (int i = tid; i < S; i += kInterpThreads) smem[i] = row[i];
     }
+  }
+  const bool full = VEC_STORE && NSTAGE > 0 && tile0 + kInterpThreads * VEC * R <= Q;
+  if (full) {  // whole tile, 16-byte stores, vector staging: nothing in the loop is conditional
+    for (int c = c0; c < c1; ++c) {
+      __syncthreads();
+      const int which = (c - c0) & 1;
+      const T* cur = smem + which * buf_elems;
+      const interp_u32x4* nrow = reinterpret_cast<const interp_u32x4*>(src + ((int64_t)b * C + min(c + 1, c1 - 1)) * S);
+#pragma unroll
+      for (int i = 0; i < (NSTAGE > 0 ? NSTAGE : 1); ++i) stg[i] = nrow[min(i * kInterpThreads + tid, nvec - 1)];
+      TPack<T, VEC> pk[R];
+      interp_channel<T, VEC, R>(cur, id, wt, pk);
+      T* orow = out + ((int64_t)b * C + c) * Q + tile0 + tid * VEC;
+#pragma unroll
+      for (int r = 0; r < R; ++r) *reinterpret_cast<TPack<T, VEC>*>(orow + r * kInterpThreads * VEC) = pk[r];
+      interp_u32x4* nxt = reinterpret_cast<interp_u32x4*>(smem + (which ^ 1) * buf_elems);
+#pragma unroll
+      for (int i = 0; i < (NSTAGE > 0 ? NSTAGE : 1); ++i) {
+        const int v = i * kInterpThreads + tid;
+        if (v < nvec) nxt[v] = stg[i];
+      }
+    }
+    return;
   }
   for (int c = c0; c < c1; ++c) {
     __syncthreads();
@@ -117,30 +162,22 @@ __global__ __launch_bounds__(kInterpThreads) void three_interp_fwd_lds_kernel(
     const T* nrow = src + ((int64_t)b * C + (have_next ? c + 1 : c)) * S;
     if (NSTAGE > 0) {
 #pragma unroll
-      for (int i = 0; i < NSTAGE; ++i) {
-        const int v = i * kInterpThreads + tid;
-        stg[i] = (have_next && v < nvec) ? reinterpret_cast<const uint4*>(nrow)[v] : make_uint4(0, 0, 0, 0);
-      }
+      for (int i = 0; i < NSTAGE; ++i)
+        stg[i] = reinterpret_cast<const interp_u32x4*>(nrow)[min(i * kInterpThreads + tid, nvec - 1)];
     }
     T* orow = out + ((int64_t)b * C + c) * Q;
+    TPack<T, VEC> pk[R];
+    interp_channel<T, VEC, R>(cur, id, wt, pk);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int q0 = tile0 + (r * kInterpThreads + tid) * VEC;
       if (q0 < Q) {
-        TPack<T, VEC> pk;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const T p0 = cur[id[r][e][0]] * wt[r][e][0];
-          const T p1 = cur[id[r][e][1]] * wt[r][e][1];
-          const T p2 = cur[id[r][e][2]] * wt[r][e][2];
-          pk.v[e] = (p0 + p1) + p2;
-        }
         if (VEC_STORE) {
-          *reinterpret_cast<TPack<T, VEC>*>(orow + q0) = pk;
+          *reinterpret_cast<TPack<T, VEC>*>(orow + q0) = pk[r];
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e)
-            if (q0 + e < Q) orow[q0 + e] = pk.v[e];
+            if (q0 + e < Q) orow[q0 + e] = pk[r].v[e];
         }
       }
     }
@@ -149,7 +186,7 @@ __global__ __launch_bounds__(kInterpThreads) void three_interp_fwd_lds_kernel(
 #pragma unroll
         for (int i = 0; i < NSTAGE; ++i) {
           const int v = i * kInterpThreads + tid;
-          if (v < nvec) reinterpret_cast<uint4*>(nxt)[v] = stg[i];
+          if (v < nvec) reinterpret_cast<interp_u32x4*>(nxt)[v] = stg[i];
         }
       } else {
         for (int i = tid; i < S; i += kInterpThreads) nxt[i] = nrow[i];
