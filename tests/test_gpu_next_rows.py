@@ -805,6 +805,19 @@ def test_global_topk_select_ties_take_lower_flat_index(ext, oracle_mod):
                 r, c, v = _topk_native(ext, score, k, largest)
                 assert np.array_equal(r, wr) and np.array_equal(c, wc), (shape, k, largest)
                 assert np.array_equal(v, ws)
+    # matrices large enough for the sampled short list (>= 2^20 cells) whose ties overflow it: the device-side fallback
+    # to the full-matrix select must give the same answer (few distinct values; one dominant value; all equal)
+    for shape, make in (((1100, 1100), lambda: rng.integers(-2, 3, size=(1100, 1100)).astype(np.float32)),
+                        ((2048, 1024), lambda: np.where(rng.random((2048, 1024)) < 0.999, 1.0, rng.random((2048, 1024))).astype(np.float32)),
+                        ((1500, 1500), lambda: np.full((1500, 1500), 0.25, dtype=np.float32))):
+        s = make()
+        score = T(s)
+        for k in (1, 300, 5000):
+            for largest in (True, False):
+                wr, wc, ws = oracle_mod.extract_correspondences_from_scores_topk(s, k, False, largest)
+                r, c, v = _topk_native(ext, score, k, largest)
+                assert np.array_equal(r, wr) and np.array_equal(c, wc), (shape, k, largest)
+                assert np.array_equal(v, ws)
     s = np.zeros((100, 100), dtype=np.float32)  # all equal: the first k cells
     r, c, _ = _topk_native(ext, T(s), 250)
     assert np.array_equal(r * 100 + c, np.arange(250))
