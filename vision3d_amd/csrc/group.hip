@@ -119,6 +119,35 @@ __device__ __forceinline__ void grp_commit(const grp_u32x4 (&stg)[NSTAGE], const
   }
 }
 
+typedef float grp_f32x4 __attribute__((ext_vector_type(4)));
+// The 32 values of one thread for one output channel (8 vectors of 4 consecutive positions).
+template <bool KV, bool CTR>
+__device__ __forceinline__ void grp_gather(const float* cur, const float* cc, bool has_row, bool has_ctr,
+                                           const int (&my)[kGrpR][kGrpVec], const int (&mq)[kGrpR][KV ? 1 : kGrpVec],
+                                           grp_f32x4 (&pk)[kGrpR]) {
+  if (!CTR || (has_row && !has_ctr)) {  // plain gather: 32 LDS reads, no tests
+#pragma unroll
+    for (int r = 0; r < kGrpR; ++r) pk[r] = grp_f32x4{cur[my[r][0]], cur[my[r][1]], cur[my[r][2]], cur[my[r][3]]};
+  } else if (has_row) {  // gather minus centre
+#pragma unroll
+    for (int r = 0; r < kGrpR; ++r) {
+#pragma unroll
+      for (int e = 0; e < kGrpVec; ++e) pk[r][e] = cur[my[r][e]] - cc[mq[r][KV ? 0 : e]];
+    }
+  } else {  // broadcast centre
+#pragma unroll
+    for (int r = 0; r < kGrpR; ++r) {
+#pragma unroll
+      for (int e = 0; e < kGrpVec; ++e) pk[r][e] = cc[mq[r][KV ? 0 : e]];
+    }
+  }
+}
+__device__ __forceinline__ void grp_store(const grp_f32x4 (&pk)[kGrpR], float* orow) {
+#pragma unroll
+  for (int r = 0; r < kGrpR; ++r)
+    __builtin_nontemporal_store(pk[r], reinterpret_cast<grp_f32x4*>(orow + (int64_t)r * kGrpThreads * kGrpVec));
+}
+
 // KV: K % 4 == 0, so the four positions of a vector share one query.
 // CTR: the launch has broadcast / offset channels (false = plain gather: no query bookkeeping at all).
 template <bool KV, bool CTR, int NSTAGE>
@@ -176,7 +205,7 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(const floa
   const int nvec = a.N >> 2;
   grp_u32x4 stg[NSTAGE];
   float cst[kGrpCtrVals];
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef grp_f32x4 f32x4;
   GrpSel nxt = grp_select<CTR>(src0, src1, ctr, a, b, c0);
   grp_issue<CTR, NSTAGE>(nxt, stg, cst, tid, nvec, m_first, m_count);
   grp_commit<CTR, NSTAGE>(stg, cst, rows, ctrs, tid, nvec, m_count);
@@ -184,40 +213,39 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(const floa
   // loads and the LDS writes that consume them, so the compiler's wait there is a COUNTED vmcnt and the stores stay in
   // flight) and the last, partial tile of a row (per-store tests; its waits drain the queue, it is one tile per row).
   if (full) {
-    for (int oc = c0; oc < c1; ++oc) {
-      __syncthreads();
-      const int which = (oc - c0) & 1;
-      const float* cur = rows + which * row_elems;
-      const float* cc = ctrs + which * ctr_elems;
-      const bool has_row = !CTR || nxt.has_row, has_ctr = CTR && nxt.has_ctr;  // of channel oc (selected last iteration)
-      // the next channel's row is requested now and written to the other buffer after this channel's stores; the last
-      // channel re-stages itself (one redundant L2 read per workgroup) so that nothing in the loop is conditional
-      nxt = grp_select<CTR>(src0, src1, ctr, a, b, min(oc + 1, c1 - 1));
-      grp_issue<CTR, NSTAGE>(nxt, stg, cst, tid, nvec, m_first, m_count);
-      float* orow = out + ((int64_t)b * Cout + oc) * L + tile0 + (int64_t)tid * kGrpVec;
-      f32x4 pk[kGrpR];
-      if (!CTR || (has_row && !has_ctr)) {  // plain gather: 32 LDS reads, then 8 stores, no tests
-#pragma unroll
-        for (int r = 0; r < kGrpR; ++r) pk[r] = f32x4{cur[my[r][0]], cur[my[r][1]], cur[my[r][2]], cur[my[r][3]]};
-      } else if (has_row) {  // gather minus centre
-#pragma unroll
-        for (int r = 0; r < kGrpR; ++r) {
-#pragma unroll
-          for (int e = 0; e < kGrpVec; ++e) pk[r][e] = cur[my[r][e]] - cc[mq[r][KV ? 0 : e]];
-        }
-      } else {  // broadcast centre
-#pragma unroll
-        for (int r = 0; r < kGrpR; ++r) {
-#pragma unroll
-          for (int e = 0; e < kGrpVec; ++e) pk[r][e] = cc[mq[r][KV ? 0 : e]];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < kGrpR; ++r)
-        __builtin_nontemporal_store(pk[r], reinterpret_cast<f32x4*>(orow + (int64_t)r * kGrpThreads * kGrpVec));
-      grp_commit<CTR, NSTAGE>(stg, cst, rows + (which ^ 1) * row_elems, ctrs + (which ^ 1) * ctr_elems, tid, nvec,
-                              m_count);
+    // Stores run ONE CHANNEL BEHIND the gathers, from two alternating register sets: the LDS reads of channel c write
+    // registers whose last stores (channel c - 2) were issued a whole iteration ago, so the wait the compiler puts in
+    // front of them leaves channel c - 1's eight stores in flight instead of draining the queue every channel.
+    f32x4 pkA[kGrpR], pkB[kGrpR];
+#define V3D_GRP_STEP(OC, DST, PREV, STORE_PREV)                                                                        \
+  do {                                                                                                                 \
+    __syncthreads();                                                                                                   \
+    const int which_ = ((OC) - c0) & 1;                                                                                \
+    const float* cur_ = rows + which_ * row_elems;                                                                     \
+    const float* cc_ = ctrs + which_ * ctr_elems;                                                                      \
+    const bool has_row_ = !CTR || nxt.has_row, has_ctr_ = CTR && nxt.has_ctr; /* of channel OC */                      \
+    /* the next channel's row is requested now and written to the other buffer at the end of the step; the last     */ \
+    /* channel re-stages itself (one redundant L2 read per workgroup): nothing here is conditional                  */ \
+    nxt = grp_select<CTR>(src0, src1, ctr, a, b, min((OC) + 1, c1 - 1));                                               \
+    grp_issue<CTR, NSTAGE>(nxt, stg, cst, tid, nvec, m_first, m_count);                                                \
+    grp_gather<KV, CTR>(cur_, cc_, has_row_, has_ctr_, my, mq, DST);                                                   \
+    if (STORE_PREV) grp_store(PREV, out + ((int64_t)b * Cout + (OC) - 1) * L + tile0 + (int64_t)tid * kGrpVec);        \
+    grp_commit<CTR, NSTAGE>(stg, cst, rows + (which_ ^ 1) * row_elems, ctrs + (which_ ^ 1) * ctr_elems, tid, nvec,     \
+                            m_count);                                                                                  \
+  } while (0)
+    int oc = c0;
+    V3D_GRP_STEP(oc, pkA, pkB, false);
+    for (oc = c0 + 1; oc + 1 < c1; oc += 2) {
+      V3D_GRP_STEP(oc, pkB, pkA, true);
+      V3D_GRP_STEP(oc + 1, pkA, pkB, true);
     }
+    if (oc < c1) {
+      V3D_GRP_STEP(oc, pkB, pkA, true);
+      grp_store(pkB, out + ((int64_t)b * Cout + oc) * L + tile0 + (int64_t)tid * kGrpVec);
+    } else {
+      grp_store(pkA, out + ((int64_t)b * Cout + c1 - 1) * L + tile0 + (int64_t)tid * kGrpVec);
+    }
+#undef V3D_GRP_STEP
   } else {
     for (int oc = c0; oc < c1; ++oc) {
       __syncthreads();
