@@ -216,6 +216,8 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(const floa
     // Stores run ONE CHANNEL BEHIND the gathers, from two alternating register sets: the LDS reads of channel c write
     // registers whose last stores (channel c - 2) were issued a whole iteration ago, so the wait the compiler puts in
     // front of them leaves channel c - 1's eight stores in flight instead of draining the queue every channel.
+    // (Not for K % 4 != 0: the per-position query table of that variant plus two value sets need 343 registers -- one
+    // wave per SIMD -- and ran 10-30 % slower than the plain loop below.)
     f32x4 pkA[kGrpR], pkB[kGrpR];
 #define V3D_GRP_STEP(OC, DST, PREV, STORE_PREV)                                                                        \
   do {                                                                                                                 \
@@ -233,17 +235,24 @@ __global__ __launch_bounds__(kGrpThreads) void group_fused_lds_kernel(const floa
     grp_commit<CTR, NSTAGE>(stg, cst, rows + (which_ ^ 1) * row_elems, ctrs + (which_ ^ 1) * ctr_elems, tid, nvec,     \
                             m_count);                                                                                  \
   } while (0)
-    int oc = c0;
-    V3D_GRP_STEP(oc, pkA, pkB, false);
-    for (oc = c0 + 1; oc + 1 < c1; oc += 2) {
-      V3D_GRP_STEP(oc, pkB, pkA, true);
-      V3D_GRP_STEP(oc + 1, pkA, pkB, true);
-    }
-    if (oc < c1) {
-      V3D_GRP_STEP(oc, pkB, pkA, true);
-      grp_store(pkB, out + ((int64_t)b * Cout + oc) * L + tile0 + (int64_t)tid * kGrpVec);
+    if constexpr (KV) {
+      int oc = c0;
+      V3D_GRP_STEP(oc, pkA, pkB, false);
+      for (oc = c0 + 1; oc + 1 < c1; oc += 2) {
+        V3D_GRP_STEP(oc, pkB, pkA, true);
+        V3D_GRP_STEP(oc + 1, pkA, pkB, true);
+      }
+      if (oc < c1) {
+        V3D_GRP_STEP(oc, pkB, pkA, true);
+        grp_store(pkB, out + ((int64_t)b * Cout + oc) * L + tile0 + (int64_t)tid * kGrpVec);
+      } else {
+        grp_store(pkA, out + ((int64_t)b * Cout + c1 - 1) * L + tile0 + (int64_t)tid * kGrpVec);
+      }
     } else {
-      grp_store(pkA, out + ((int64_t)b * Cout + c1 - 1) * L + tile0 + (int64_t)tid * kGrpVec);
+      for (int oc = c0; oc < c1; ++oc) {  // one register set, stores right behind the gathers
+        V3D_GRP_STEP(oc, pkA, pkA, false);
+        grp_store(pkA, out + ((int64_t)b * Cout + oc) * L + tile0 + (int64_t)tid * kGrpVec);
+      }
     }
 #undef V3D_GRP_STEP
   } else {
