@@ -704,3 +704,41 @@ def test_feature_knn_full_config_sizes(ext, oracle_mod):
     assert torch.all(d[..., 1:] >= d[..., :-1])
     exact = (xd[0, :, None, :] - yd[0][idx[0]]).pow(2).sum(-1).sqrt()  # (n, k) exact difference form
     torch.testing.assert_close(d[0], exact, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("S", [3, 63, 64, 100, 383, 384, 900, 1024, 1600, 2048, 2049])
+def test_three_nn_cell_list_sizes_and_degenerate_clouds(ext, oracle_mod, S):
+    """three_nn switches to the in-LDS cell list for 64 <= S <= 2048 (fp32): every size class, clustered / flat /
+    duplicated supports, queries far outside the supports' bounding box, infinite and NaN coordinates -- all equal to
+    the oracle's sequential scan, ties included."""
+    rng = np.random.default_rng(S)
+    B, Qn = 2, 300
+    cases = {
+        "uniform": rng.random((B, S, 3), dtype=np.float32),
+        "flat": np.concatenate([rng.random((B, S, 2), dtype=np.float32), np.full((B, S, 1), 0.5, np.float32)], axis=2),
+        "clustered": (rng.random((B, S, 3), dtype=np.float32) * 1e-3 + (np.arange(S)[None, :, None] % 3)).astype(np.float32),
+        "lattice": (rng.integers(0, 4, size=(B, S, 3)).astype(np.float32) * 0.25),  # massive ties and duplicates
+        "one_point": np.full((B, S, 3), 0.25, dtype=np.float32),
+    }
+    for name, s in cases.items():
+        q = np.concatenate([s[:, : min(S, 100)], rng.random((B, Qn - 100, 3), dtype=np.float32) * 3 - 1,
+                            np.full((B, 100 - min(S, 100), 3), 7.0, np.float32)], axis=1).astype(np.float32)
+        want_d, want_i = oracle_mod.three_nn(q, s)
+        d = torch.empty((B, q.shape[1], 3), device=DEV)
+        i = torch.zeros((B, q.shape[1], 3), dtype=torch.long, device=DEV)
+        ext.three_nn(T(q), T(s), d, i)
+        assert np.array_equal(N_(i), want_i), (name, S)
+        assert np.array_equal(N_(d), want_d), (name, S)
+    if S >= 64:
+        s = rng.random((1, S, 3), dtype=np.float32)
+        s[0, 5] = np.inf
+        s[0, 9, 1] = np.nan
+        q = rng.random((1, 50, 3), dtype=np.float32)
+        q[0, 3, 0] = np.nan
+        q[0, 4, 2] = np.inf
+        want_d, want_i = oracle_mod.three_nn(q, s)
+        d = torch.empty((1, 50, 3), device=DEV)
+        i = torch.zeros((1, 50, 3), dtype=torch.long, device=DEV)
+        ext.three_nn(T(q), T(s), d, i)
+        assert np.array_equal(N_(i), want_i), ("nonfinite", S)
+        assert np.array_equal(N_(d), want_d, equal_nan=True), ("nonfinite", S)

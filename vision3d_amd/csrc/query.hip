@@ -16,6 +16,8 @@
 //                  ties come out in exactly the reference's order.
 // Squared distances use the reference's expression order with one rounding per operation (the library is
 // compiled with -ffp-contract=off).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -386,6 +388,206 @@ __global__ __launch_bounds__(kQueryThreads) void three_nn_kernel(const T* __rest
   }
 }
 
+// Cell-list variant (fp32, 64 <= S <= 2048).  Every workgroup (256 queries of one cloud) sorts the cloud's supports into
+// a G^3 uniform grid over their bounding box, all in LDS (count, scan, scatter: integer LDS atomics only), then each
+// thread walks the cells around its query ring by ring -- 27 cells hold ~2 supports each for PointNet++'s 1024 sampled
+// centroids, against 1024 candidates of the brute-force scan -- and stops as soon as its third-best distance is below
+// the distance to the nearest unexplored cell face (minus a safety margin that covers the rounding of the cell
+// assignment).  Candidates arrive in cell order, not index order, so insertion compares (distance, index)
+// lexicographically: the result is the brute-force one bit for bit, ties included (lower index first).
+template <int G>
+__global__ __launch_bounds__(kQueryThreads) void three_nn_grid_kernel(const float* __restrict__ q,
+                                                                      const float* __restrict__ s,
+                                                                      float* __restrict__ out_d,
+                                                                      int64_t* __restrict__ out_i, int Q, int S) {
+  constexpr int NC = G * G * G;
+  constexpr int kMaxPer = 2048 / kQueryThreads;  // supports per thread
+  extern __shared__ float4 nn_sorted[];          // S entries: x, y, z, index bits
+  __shared__ int cell_start[NC + 1];
+  __shared__ int cursor[NC];
+  __shared__ float red[6][kWavesPerBlock];
+  __shared__ int wave_sum[kWavesPerBlock];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const float* s_cloud = s + (int64_t)b * S * 3;
+
+  // ---- supports of this thread, bounding box --------------------------------------------------------------------
+  float sx[kMaxPer], sy[kMaxPer], sz[kMaxPer];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int u = 0; u < kMaxPer; ++u) {
+    const int i = u * kQueryThreads + tid;
+    if (i < S) {
+      sx[u] = s_cloud[i * 3 + 0];
+      sy[u] = s_cloud[i * 3 + 1];
+      sz[u] = s_cloud[i * 3 + 2];
+      lo[0] = fminf(lo[0], sx[u]); hi[0] = fmaxf(hi[0], sx[u]);
+      lo[1] = fminf(lo[1], sy[u]); hi[1] = fmaxf(hi[1], sy[u]);
+      lo[2] = fminf(lo[2], sz[u]); hi[2] = fmaxf(hi[2], sz[u]);
+    } else {
+      sx[u] = sy[u] = sz[u] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+    }
+    if (lane == 0) {
+      red[a][wave] = lo[a];
+      red[3 + a][wave] = hi[a];
+    }
+  }
+  for (int i = tid; i < NC; i += kQueryThreads) cell_start[i] = 0;
+  __syncthreads();
+  float cell[3], inv[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = red[a][0];
+    hi[a] = red[3 + a][0];
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+      lo[a] = fminf(lo[a], red[a][w]);
+      hi[a] = fmaxf(hi[a], red[3 + a][w]);
+    }
+    const float ext = hi[a] - lo[a];
+    cell[a] = ext > 0.f ? ext / (float)G : 1.0f;  // a flat axis: everything lands in cell 0 of that axis
+    inv[a] = 1.0f / cell[a];
+  }
+  auto coord = [&](float v, int a) { return max(0, min(G - 1, (int)floorf((v - lo[a]) * inv[a]))); };
+
+  // ---- counting sort of the supports by cell (LDS only) ---------------------------------------------------------
+  int cid[kMaxPer];
+#pragma unroll
+  for (int u = 0; u < kMaxPer; ++u) {
+    const int i = u * kQueryThreads + tid;
+    cid[u] = (coord(sz[u], 2) * G + coord(sy[u], 1)) * G + coord(sx[u], 0);
+    if (i < S) atomicAdd(&cell_start[cid[u]], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan of the NC counts: thread t owns cells 2t, 2t+1 (NC <= 512)
+    const int c0 = 2 * tid < NC ? cell_start[2 * tid] : 0, c1 = 2 * tid + 1 < NC ? cell_start[2 * tid + 1] : 0;
+    const int mine = c0 + c1;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    for (int w = 0; w < wave; ++w) before += wave_sum[w];
+    if (2 * tid < NC) {
+      cell_start[2 * tid] = before;
+      cursor[2 * tid] = before;
+    }
+    if (2 * tid + 1 < NC) {
+      cell_start[2 * tid + 1] = before + c0;
+      cursor[2 * tid + 1] = before + c0;
+    }
+    if (tid == 0) cell_start[NC] = S;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMaxPer; ++u) {
+    const int i = u * kQueryThreads + tid;
+    if (i < S) {
+      const int pos = atomicAdd(&cursor[cid[u]], 1);
+      nn_sorted[pos] = make_float4(sx[u], sy[u], sz[u], __int_as_float(i));
+    }
+  }
+  __syncthreads();
+
+  // ---- queries ---------------------------------------------------------------------------------------------------
+  const int qi = blockIdx.x * kQueryThreads + tid;
+  if (qi >= Q) return;  // no barrier below
+  const float* qp = q + ((int64_t)b * Q + qi) * 3;
+  const float qv[3] = {qp[0], qp[1], qp[2]};
+  const int cc[3] = {coord(qv[0], 0), coord(qv[1], 1), coord(qv[2], 2)};
+  // the three best as 64-bit keys (distance bits << 32 | index): distances are >= 0, so the unsigned order of the keys
+  // IS the lexicographic (distance, index) order; unfilled = (+inf, 0xffffffff); a NaN distance sorts above +inf and is
+  // never inserted, like under the brute-force kernel's strict '<'
+  const unsigned long long kEmpty = ((unsigned long long)0x7f800000u << 32) | 0xffffffffull;
+  unsigned long long k1 = kEmpty, k2 = kEmpty, k3 = kEmpty;
+  auto offer = [&](const float4 p, bool on) {
+    const float d = sq_dist(qv[0], qv[1], qv[2], p.x, p.y, p.z);
+    // d < inf: an infinite (or NaN) distance is never below the brute-force kernel's initial +inf either
+    const unsigned long long key = (on && d < INFINITY)
+        ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w)) : ~0ull;
+    const bool lt1 = key < k1, lt2 = key < k2, lt3 = key < k3;  // k1 <= k2 <= k3, so lt1 => lt2 => lt3
+    k3 = lt2 ? k2 : (lt3 ? key : k3);
+    k2 = lt1 ? k1 : (lt2 ? key : k2);
+    k1 = lt1 ? key : k1;
+  };
+  auto scan = [&](int first_cell, int last_cell) {
+    const int end = cell_start[last_cell + 1];
+    for (int j = cell_start[first_cell]; j < end; j += 4) {  // four candidates per step, all reads issued first
+      const float4 pa = nn_sorted[j];
+      const float4 pb = nn_sorted[min(j + 1, end - 1)];
+      const float4 pc = nn_sorted[min(j + 2, end - 1)];
+      const float4 pd = nn_sorted[min(j + 3, end - 1)];
+      offer(pa, true);
+      offer(pb, j + 1 < end);
+      offer(pc, j + 2 < end);
+      offer(pd, j + 3 < end);
+    }
+  };
+  int p0[3] = {1, 1, 1}, p1[3] = {0, 0, 0};  // previous region (empty)
+  for (int R = 1; R <= G; ++R) {
+    int r0[3], r1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      r0[a] = max(cc[a] - R, 0);
+      r1[a] = min(cc[a] + R, G - 1);
+    }
+    for (int z = r0[2]; z <= r1[2]; ++z) {
+      for (int y = r0[1]; y <= r1[1]; ++y) {
+        const int row = (z * G + y) * G;
+        const bool inner = z >= p0[2] && z <= p1[2] && y >= p0[1] && y <= p1[1];
+        if (!inner) {
+          scan(row + r0[0], row + r1[0]);  // cells of one (z, y) row are contiguous in the sorted order
+        } else {
+          if (cc[0] - R >= 0) scan(row + cc[0] - R, row + cc[0] - R);
+          if (cc[0] + R <= G - 1) scan(row + cc[0] + R, row + cc[0] + R);
+        }
+      }
+    }
+    // nearest face of the explored box that still has cells behind it
+    float bound = INFINITY;
+    bool open = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float margin = 1e-5f * (hi[a] - lo[a]);
+      if (r0[a] > 0) {
+        open = true;
+        bound = fminf(bound, fmaxf(qv[a] - (lo[a] + (float)r0[a] * cell[a]) - margin, 0.f));
+      }
+      if (r1[a] < G - 1) {
+        open = true;
+        bound = fminf(bound, fmaxf((lo[a] + (float)(r1[a] + 1) * cell[a]) - qv[a] - margin, 0.f));
+      }
+    }
+    const float b3 = __uint_as_float((unsigned)(k3 >> 32));
+    if (!open || b3 < bound * bound) break;  // (NaN bounds compare false: the search widens to the whole grid)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      p0[a] = r0[a];
+      p1[a] = r1[a];
+    }
+  }
+  const float unfilled = 1e20f;
+  float* od = out_d + ((int64_t)b * Q + qi) * 3;
+  int64_t* oi = out_i + ((int64_t)b * Q + qi) * 3;
+  const int i1 = (int)(unsigned)k1, i2 = (int)(unsigned)k2, i3 = (int)(unsigned)k3;  // -1 where unfilled
+  od[0] = i1 >= 0 ? sqrtf(__uint_as_float((unsigned)(k1 >> 32))) : unfilled;
+  od[1] = i2 >= 0 ? sqrtf(__uint_as_float((unsigned)(k2 >> 32))) : unfilled;
+  od[2] = i3 >= 0 ? sqrtf(__uint_as_float((unsigned)(k3 >> 32))) : unfilled;
+  oi[0] = i1;
+  oi[1] = i2;
+  oi[2] = i3;
+}
+
 template <typename T>
 static int three_nn(const T* q, const T* s, T* od, int64_t* oi, int B, int Q, int S, int device, void* stream_) {
   const char* what = "three_nn";
@@ -401,6 +603,21 @@ static int three_nn(const T* q, const T* s, T* od, int64_t* oi, int B, int Q, in
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   constexpr int TS = 1024;
   dim3 grid((unsigned)ceil_div(Q, kQueryThreads), (unsigned)B), block(kQueryThreads);
+  if constexpr (std::is_same<T, float>::value) {
+    if (S >= 64 && S <= 2048) {  // cell list in LDS; smaller sets are launch-bound either way, larger ones do not fit
+      const size_t lds = (size_t)S * sizeof(float4);
+      // a few supports per cell: the 27 cells around a query then hold its three nearest almost always (one ring);
+      // measured at S = 1024: G = 4 79 us, 5 51-53, 6 51-57, 7 55-62, 8 63 (brute force: 92)
+      static const int tune = getenv("V3D_TNN_G") ? atoi(getenv("V3D_TNN_G")) : 0;  // tuning aid
+      const int g = tune ? tune : (S >= 1600 ? 7 : (S >= 900 ? 6 : (S >= 384 ? 5 : 4)));  // ~5-8 supports per cell
+      if (g == 8) hipLaunchKernelGGL((three_nn_grid_kernel<8>), grid, block, lds, stream, q, s, od, oi, Q, S);
+      else if (g == 7) hipLaunchKernelGGL((three_nn_grid_kernel<7>), grid, block, lds, stream, q, s, od, oi, Q, S);
+      else if (g == 6) hipLaunchKernelGGL((three_nn_grid_kernel<6>), grid, block, lds, stream, q, s, od, oi, Q, S);
+      else if (g == 5) hipLaunchKernelGGL((three_nn_grid_kernel<5>), grid, block, lds, stream, q, s, od, oi, Q, S);
+      else hipLaunchKernelGGL((three_nn_grid_kernel<4>), grid, block, lds, stream, q, s, od, oi, Q, S);
+      return launch_status(what);
+    }
+  }
   hipLaunchKernelGGL((three_nn_kernel<T, TS>), grid, block, 0, stream, q, s, od, oi, Q, S);
   return launch_status(what);
 }
