@@ -719,9 +719,13 @@ def test_three_nn_cell_list_sizes_and_degenerate_clouds(ext, oracle_mod, S):
         "clustered": (rng.random((B, S, 3), dtype=np.float32) * 1e-3 + (np.arange(S)[None, :, None] % 3)).astype(np.float32),
         "lattice": (rng.integers(0, 4, size=(B, S, 3)).astype(np.float32) * 0.25),  # massive ties and duplicates
         "one_point": np.full((B, S, 3), 0.25, dtype=np.float32),
+        # far from the coordinate origin: coordinates quantised at 1/16, face positions must not be rounded at 1e6
+        "offset": (rng.random((B, S, 3), dtype=np.float32) * 40 + np.float32(1e6)).astype(np.float32),
+        "anisotropic": (rng.random((B, S, 3), dtype=np.float32) * np.float32([1000.0, 1.0, 1e-3])).astype(np.float32),
     }
     for name, s in cases.items():
-        q = np.concatenate([s[:, : min(S, 100)], rng.random((B, Qn - 100, 3), dtype=np.float32) * 3 - 1,
+        centre, span = s.mean(axis=1, keepdims=True), (s.max(axis=1, keepdims=True) - s.min(axis=1, keepdims=True))
+        q = np.concatenate([s[:, : min(S, 100)], (centre + (rng.random((B, Qn - 100, 3), dtype=np.float32) * 3 - 1.5) * span),
                             np.full((B, 100 - min(S, 100), 3), 7.0, np.float32)], axis=1).astype(np.float32)
         want_d, want_i = oracle_mod.three_nn(q, s)
         d = torch.empty((B, q.shape[1], 3), device=DEV)

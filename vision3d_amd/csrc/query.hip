@@ -558,14 +558,17 @@ __global__ __launch_bounds__(kQueryThreads) void three_nn_grid_kernel(const floa
     bool open = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float margin = 1e-5f * (hi[a] - lo[a]);
+      // everything relative to the box origin (clouds far from the coordinate origin: lo + j * cell would be rounded at
+      // the magnitude of lo); the margin covers the rounding of the cell assignment and of the two sides of the test
+      const float rel = qv[a] - lo[a];
+      const float margin = 1e-5f * fmaxf(hi[a] - lo[a], fabsf(rel));
       if (r0[a] > 0) {
         open = true;
-        bound = fminf(bound, fmaxf(qv[a] - (lo[a] + (float)r0[a] * cell[a]) - margin, 0.f));
+        bound = fminf(bound, fmaxf(rel - (float)r0[a] * cell[a] - margin, 0.f));
       }
       if (r1[a] < G - 1) {
         open = true;
-        bound = fminf(bound, fmaxf((lo[a] + (float)(r1[a] + 1) * cell[a]) - qv[a] - margin, 0.f));
+        bound = fminf(bound, fmaxf((float)(r1[a] + 1) * cell[a] - rel - margin, 0.f));
       }
     }
     const float b3 = __uint_as_float((unsigned)(k3 >> 32));
