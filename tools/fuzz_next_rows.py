@@ -23,7 +23,68 @@ def table(rng, m, k, n):
 
 
 def one_case(rng, i):
-    kind = i % 6
+    kind = i % 10
+    if kind == 6:  # threshold selection and global top-k on one matrix (ties on purpose: quantised scores)
+        n, m = int(rng.integers(1, 1300)), int(rng.integers(1, 1300))
+        score = np.round(rng.standard_normal((n, m)) * rng.choice([1, 4, 50, 1000])).astype(np.float32) / 4
+        largest = bool(rng.integers(2))
+        thr = float(rng.standard_normal())
+        wr, wc, ws = oracle.threshold_select(score, thr, largest)
+        idx = torch.empty((2, max(score.size, 1)), dtype=torch.long, device=DEV)
+        sc = torch.empty((max(score.size, 1),), device=DEV)
+        cnt = torch.zeros((), dtype=torch.long, device=DEV)
+        ext.threshold_select(T(score), thr, out_row=idx[0], out_col=idx[1], out_score=sc, num_out=cnt, largest=largest)
+        c_ = int(cnt.item())
+        ok = c_ == len(wr) and np.array_equal(N_(idx[0, :c_]), wr) and np.array_equal(N_(idx[1, :c_]), wc) and \
+            np.array_equal(N_(sc[:c_]), ws)
+        k = int(rng.integers(1, min(score.size, 6000) + 1))
+        dust = bool(rng.integers(2))
+        r, c, v = ops.extract_correspondences_from_scores_topk(T(score), k, has_dustbin=dust, largest=largest,
+                                                               return_score=True)
+        wr, wc, ws = oracle.extract_correspondences_from_scores_topk(score, k, dust, largest)
+        ok = ok and np.array_equal(N_(r), wr) and np.array_equal(N_(c), wc) and np.array_equal(N_(v), ws)
+        return ok, f"matchsel n{n} m{m} k{k} l{largest} thr{thr} dust{dust}"
+    if kind == 7:  # voxelisation
+        b = int(rng.integers(1, 6))
+        lengths = rng.integers(0, 3000, size=b).astype(np.int64)
+        total = int(lengths.sum())
+        c = int(rng.integers(1, 40))
+        pts = ((rng.random((total, 3), dtype=np.float32) - 0.5) * np.float32(rng.choice([1, 10, 100]))).astype(np.float32)
+        if rng.integers(2) and total:
+            pts = np.round(pts * 8) / 8  # points on voxel faces
+        feats = rng.standard_normal((total, c)).astype(np.float32)
+        vs = float(rng.choice([0.05, 0.125, 0.3, 1.0]))
+        want = oracle.voxelize_pack(pts, lengths, vs, feats)
+        got = ops.voxelize_pack_mode(T(pts), T(lengths), vs, feats=T(feats))
+        ok = all(np.array_equal(N_(g), w) for g, w in zip(got, want))
+        return ok, f"voxelize b{b} total{total} c{c} vs{vs}"
+    if kind == 8:  # three_nn: every size class of the cell list, clustered / quantised supports
+        b, q, s_ = int(rng.integers(1, 4)), int(rng.integers(1, 900)), int(rng.integers(1, 2300))
+        sup = rng.random((b, s_, 3), dtype=np.float32) * np.float32(rng.choice([1e-3, 1, 1e3]))
+        if rng.integers(2):
+            sup = np.round(sup / sup.max() * 6) * np.float32(0.25)
+        sup = (sup + np.float32(rng.choice([0, 5, 1e5]))).astype(np.float32)
+        lo, hi = sup.min(), sup.max()
+        qs = (lo + (rng.random((b, q, 3), dtype=np.float32) * 2 - 0.5) * (hi - lo + 1e-3)).astype(np.float32)
+        wd, wi = oracle.three_nn(qs, sup)
+        d = torch.empty((b, q, 3), device=DEV)
+        i_ = torch.zeros((b, q, 3), dtype=torch.long, device=DEV)
+        ext.three_nn(T(qs), T(sup), d, i_)
+        ok = np.array_equal(N_(i_), wi) and np.array_equal(N_(d), wd)
+        return ok, f"three_nn b{b} q{q} s{s_}"
+    if kind == 9:  # multi-scale ball query
+        b, m, n = int(rng.integers(1, 4)), int(rng.integers(1, 300)), int(rng.integers(1, 3000))
+        sup = rng.random((b, n, 3), dtype=np.float32)
+        if rng.integers(2):
+            sup = (np.round(sup * 5) / 5).astype(np.float32)
+        qs = sup[:, rng.integers(0, n, size=m)] + (rng.random((b, m, 3), dtype=np.float32) < 0.1) * np.float32(3.0)
+        qs = qs.astype(np.float32)
+        ns = int(rng.integers(1, 5))
+        ks = [int(rng.integers(1, 140)) for _ in range(ns)]
+        rs = [float(rng.choice([0.01, 0.1, 0.2, 0.4, 2.0])) for _ in range(ns)]
+        got = ops.ball_query_multi(T(qs), T(sup), ks, rs)
+        ok = all(np.array_equal(N_(g), oracle.ball_query(qs, sup, k, r)) for g, k, r in zip(got, ks, rs))
+        return ok, f"ball_multi b{b} m{m} n{n} ks{ks} rs{rs}"
     if kind == 0:  # selection on a matrix
         b, n, m = int(rng.integers(1, 4)), int(rng.integers(1, 400)), int(rng.integers(1, 400))
         k = int(rng.integers(1, min(n, m, 64) + 1))
