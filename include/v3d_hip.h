@@ -176,6 +176,12 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
                                const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q,
                                int64_t total_s, float radius, int neighbor_limit, void* workspace,
                                size_t workspace_bytes, int device, void* stream);
+/* Radius count, replaces vision3d/ops/radius_search.py:74-107 (pack -> padded batch -> pykeops sum of
+ * relu(radius - d).sign() -> pack): counts (total_q,) = the number of supports of the query's own cloud with
+ * radius - sqrt(d2) > 0 (strict).  Same cell list, workspace and limits as the search above. */
+int v3d_radius_count_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths,
+                              const int64_t* s_lengths, int64_t* counts, int B, int64_t total_q, int64_t total_s,
+                              float radius, void* workspace, size_t workspace_bytes, int device, void* stream);
 
 /* Grid (voxel) subsampling, replaces vision3d/ops/grid_subsample.py:49-99: one output point per occupied voxel of
  * edge `voxel_size` = mean of the voxel's points (summed in input order, fp32), ordered by (cloud, vx, vy, vz) like

@@ -231,6 +231,6 @@ def grid_subsample_pack(points, lengths, voxel_size):
 
 
 from .next_rows import (edge_group, extract_correspondences_from_scores, extract_correspondences_from_scores_threshold,
-                        extract_correspondences_from_scores_topk, threshold_select, voxelize_pack, kpconv_gather, sa_group, global_avgpool_pack, index_select_rows, knn_interp_weights_pack,  # noqa: E402,F401
+                        extract_correspondences_from_scores_topk, radius_count_pack, threshold_select, voxelize_pack, kpconv_gather, sa_group, global_avgpool_pack, index_select_rows, knn_interp_weights_pack,  # noqa: E402,F401
                         knn_interpolate_pack, local_maxpool_pack, mutual_topk_corr_mat, mutual_topk_select, point_to_node_partition,
                         nearest_interpolate_pack, rows_scatter, rows_weighted_sum, sample_nodes_with_fps)  # SURVEY 8f ranks 2-4, NumPy

@@ -322,3 +322,24 @@ def voxelize_pack(points, lengths, voxel_size, feats=None):
         v_feats /= counts[:, None].astype(np.float32)                                      # :60
         out.append(v_feats)
     return tuple(out) + (v_lengths,)
+
+
+def radius_count_pack(q_points, s_points, q_lengths, s_lengths, radius):
+    """ops/radius_search.py:74-107: per query, the number of supports of its own cloud with radius - d > 0, where
+    d = sqrt((dx*dx + dy*dy) + dz*dz) in fp32 (the padded rows of the reference sit at 1e10 and never count)."""
+    q = np.asarray(q_points, np.float32)
+    s = np.asarray(s_points, np.float32)
+    r = np.float32(radius)
+    out = np.zeros((q.shape[0],), np.int64)
+    qo = so = 0
+    for ql, sl in zip(np.asarray(q_lengths).tolist(), np.asarray(s_lengths).tolist()):
+        cq, cs = q[qo:qo + ql], s[so:so + sl]
+        for a in range(0, ql, 1024):
+            blk = cq[a:a + 1024, None, :] - cs[None, :, :]  # fp32
+            d2 = (blk[..., 0] * blk[..., 0] + blk[..., 1] * blk[..., 1]) + blk[..., 2] * blk[..., 2]
+            with np.errstate(invalid="ignore"):
+                out[qo + a:qo + a + blk.shape[0]] = ((r - np.sqrt(d2)) > 0).sum(1)
+        qo += ql
+        so += sl
+    return out
+

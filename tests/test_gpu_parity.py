@@ -637,6 +637,57 @@ def test_radius_search_pack_native(ext, oracle_mod, case):
     assert np.array_equal(N_(out), want)
 
 
+@pytest.mark.parametrize("case", [
+    dict(q=(300, 0, 200), s=(500, 10, 400), r=0.15),          # empty query cloud, tiny support cloud
+    dict(q=(64, 1, 1000), s=(0, 7, 3000), r=0.1),             # empty support cloud -> zero
+    dict(q=(500,), s=(500,), r=0.25, lattice=8),              # lattice: pairs exactly at the radius (strict: out)
+    dict(q=(400, 400), s=(2000, 1500), r=0.05),
+    dict(q=(300,), s=(4000,), r=2.0),                         # radius covers the whole cloud: one coarse cell
+    dict(q=(200, 200), s=(3000, 3000), r=0.0625, scale=3.0),  # config-4-like proportions
+    dict(q=(100,), s=(100,), r=0.0, lattice=4),               # zero radius: nothing is strictly inside
+])
+def test_radius_count_pack_native(ext, oracle_mod, case):
+    """v3d_radius_count_pack_f32 (cell list) == the NumPy restatement of radius_search.py:74-107, bit for bit, and ==
+    the padded brute-force route the op used before."""
+    from vision3d_amd import ops
+    from vision3d_amd.ops.radius_search import padded_radius_count_pack_mode
+
+    rng = np.random.default_rng(63)
+    q, s, ql, sl = _pack_clouds(rng, case["q"], case["s"], case.get("lattice"), case.get("scale", 1.0))
+    q[:10] += 0.7 * case.get("scale", 1.0)  # some queries outside the support box
+    want = oracle_mod.radius_count_pack(q, s, ql, sl, case["r"])
+    out = torch.full((q.shape[0],), -7, dtype=torch.long, device=DEV)
+    ext.radius_count_pack(T(q), T(s), T(ql), T(sl), out, case["r"])
+    assert np.array_equal(N_(out), want)
+    got = ops.radius_count_pack_mode(T(q), T(s), T(ql), T(sl), case["r"])
+    assert got.shape == (q.shape[0],) and np.array_equal(N_(got), want)
+    if min(case["s"]) > 0 and min(case["q"]) > 0:
+        assert torch.equal(padded_radius_count_pack_mode(T(q), T(s), T(ql), T(sl), case["r"]), got)
+    if case["r"] > 0:  # count == number of hits of the search when the limit is not reached
+        k = int(min(128, max(1, want.max())))
+        idx = torch.empty((q.shape[0], k), dtype=torch.long, device=DEV)
+        ext.radius_search_pack(T(q), T(s), T(ql), T(sl), idx, case["r"], k)
+        hits = (N_(idx) < s.shape[0]).sum(1)
+        assert np.all(hits >= np.minimum(want, k))  # the search keeps d == radius, the count does not
+
+
+def test_radius_count_pack_nonfinite_and_refusals(ext, oracle_mod):
+    rng = np.random.default_rng(64)
+    q, s, ql, sl = _pack_clouds(rng, (200, 100), (700, 300))
+    s[5] = np.nan
+    s[17, 1] = np.inf
+    q[3, 0] = np.nan
+    q[9] = -np.inf
+    want = oracle_mod.radius_count_pack(q, s, ql, sl, 0.2)
+    out = torch.empty((300,), dtype=torch.long, device=DEV)
+    ext.radius_count_pack(T(q), T(s), T(ql), T(sl), out, 0.2)
+    assert np.array_equal(N_(out), want)
+    with pytest.raises(RuntimeError):
+        ext.radius_count_pack(T(q), T(s), T(ql), T(sl), out, -1.0)
+    with pytest.raises(RuntimeError):
+        ext.radius_count_pack(T(q), T(s), T(ql), T(sl), out[:10], 0.2)
+
+
 def test_radius_search_pack_mode_op_matches_padded_route(ext, oracle_mod):
     """ops.radius_search_pack_mode (native) == the reference's formulation (kNN over padded batches + mask) on
     tie-free inputs, and queries outside the supports' bounding box are handled."""

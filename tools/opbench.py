@@ -107,6 +107,15 @@ def main():
             lambda pts=pts, lengths=lengths, out=out, r=r, lim=lim: ext.radius_search_pack(pts, pts, lengths, lengths,
                                                                                            out, r, lim),
             nc * n, "Mq/s")
+        cnt = torch.empty((nc * n,), dtype=torch.long, device=DEV)
+        add(f"radius_count_pack clouds{nc} n{n} r{r}",
+            lambda pts=pts, lengths=lengths, cnt=cnt, r=r: ext.radius_count_pack(pts, pts, lengths, lengths, cnt, r),
+            nc * n, "Mq/s")
+        if r < 0.1:
+            from vision3d_amd.ops.radius_search import padded_radius_count_pack_mode
+            add(f"radius_count padded brute-force route clouds{nc} n{n} r{r}",
+                lambda pts=pts, lengths=lengths, r=r: padded_radius_count_pack_mode(pts, pts, lengths, lengths, r),
+                nc * n, "Mq/s")
     for (nc, n, vs) in ((16, 30000, 0.025), (16, 30000, 0.1)):
         pts = (torch.rand((nc * n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
         lengths = torch.full((nc,), n, dtype=torch.long, device=DEV)

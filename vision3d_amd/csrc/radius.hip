@@ -15,6 +15,9 @@
 //                          `limit`-th entry.  The result does not depend on the order candidates arrive in.
 // Distances use the reference expression order (dx*dx + dy*dy) + dz*dz with one rounding per operation.
 #include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 
@@ -34,10 +37,12 @@ static int64_t rs_cell_capacity(int B, int64_t total_s) { return 4096ll * B + 4l
 
 struct RsWorkspace {
   RsPlan* plan;     // [B]
-  float* bbox;      // [B][6]
+  int* bbox;        // [B][6], order-preserving int encoding of the corners
   int* cell_count;  // [cap]
   int* cell_start;  // [cap + 1]
   float4* sorted;   // [total_s]
+  void* scan_tmp;   // rocprim exclusive_scan over the cell counters
+  size_t scan_bytes;
   size_t bytes;
 };
 
@@ -51,24 +56,45 @@ static RsWorkspace rs_carve(void* base, int B, int64_t total_s) {
   };
   const size_t cap = (size_t)rs_cell_capacity(B, total_s);
   w.plan = static_cast<RsPlan*>(take(sizeof(RsPlan) * (size_t)B));
-  w.bbox = static_cast<float*>(take(sizeof(float) * 6 * (size_t)B));
+  w.bbox = static_cast<int*>(take(sizeof(int) * 6 * (size_t)B));
   w.cell_count = static_cast<int*>(take(sizeof(int) * cap));
   w.cell_start = static_cast<int*>(take(sizeof(int) * (cap + 1)));
   w.sorted = static_cast<float4*>(take(sizeof(float4) * (size_t)std::max<int64_t>(total_s, 1)));
+  w.scan_bytes = 0;
+  int* ni = nullptr;
+  if (rocprim::exclusive_scan(nullptr, w.scan_bytes, ni, ni, 0, cap, rocprim::plus<int>(), nullptr) != hipSuccess)
+    w.scan_bytes = 0;  // reported by the scan itself
+  w.scan_tmp = take(std::max<size_t>(w.scan_bytes, 256));
   w.bytes = off;
   return w;
 }
 
-// One workgroup per cloud: min / max corner of its supports.
+// Corner of a cloud's bounding box as an int whose signed order is the float order (NaN never gets here: fminf / fmaxf
+// drop it), so that several workgroups per cloud can combine their corners with integer atomics.
+__device__ __forceinline__ int rs_ordered(float f) {
+  const int b = __float_as_int(f);
+  return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float rs_unordered(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
+
+constexpr int kRsBboxSplit = 16;  // workgroups per cloud
+
+__global__ void rs_bbox_init_kernel(int* __restrict__ bbox, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * 6) bbox[i] = rs_ordered(i % 6 < 3 ? INFINITY : -INFINITY);
+}
+
+// kRsBboxSplit workgroups per cloud: min / max corner of its supports.
 __global__ __launch_bounds__(kRsThreads) void rs_bbox_kernel(const float* __restrict__ s, const int64_t* __restrict__ s_len,
-                                                             float* __restrict__ bbox) {
+                                                             int* __restrict__ bbox) {
   __shared__ float red[6][kRsThreads / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   long long off = 0;
   for (int i = 0; i < b; ++i) off += s_len[i];
   const long long n = s_len[b];
+  if ((long long)blockIdx.y * kRsThreads >= n) return;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (long long i = tid; i < n; i += kRsThreads) {
+  for (long long i = (long long)blockIdx.y * kRsThreads + tid; i < n; i += (long long)kRsThreads * kRsBboxSplit) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float v = s[(off + i) * 3 + a];
@@ -91,7 +117,8 @@ __global__ __launch_bounds__(kRsThreads) void rs_bbox_kernel(const float* __rest
   if (tid < 6) {
     float v = red[tid][0];
     for (int w = 1; w < kRsThreads / 64; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
-    bbox[b * 6 + tid] = v;
+    if (tid < 3) atomicMin(&bbox[b * 6 + tid], rs_ordered(v));
+    else atomicMax(&bbox[b * 6 + tid], rs_ordered(v));
   }
 }
 
@@ -102,7 +129,7 @@ __device__ __forceinline__ int rs_cell_coord(float p, float o, float inv_h) {
 }
 
 // One thread: grids, cell offsets and point offsets of all clouds (B is small; everything else waits on this anyway).
-__global__ void rs_plan_kernel(const float* __restrict__ bbox, const int64_t* __restrict__ q_len,
+__global__ void rs_plan_kernel(const int* __restrict__ bbox, const int64_t* __restrict__ q_len,
                                const int64_t* __restrict__ s_len, RsPlan* __restrict__ plan, int* __restrict__ cell_start,
                                int B, float radius, long long total_s) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -118,7 +145,8 @@ __global__ void rs_plan_kernel(const float* __restrict__ bbox, const int64_t* __
     p.inv_h = 1.f;
     p.dx = p.dy = p.dz = 1;
     if (p.s_len > 0) {
-      const float* bb = bbox + b * 6;
+      float bb[6];
+      for (int a = 0; a < 6; ++a) bb[a] = rs_unordered(bbox[b * 6 + a]);
       p.ox = bb[0];
       p.oy = bb[1];
       p.oz = bb[2];
@@ -139,7 +167,7 @@ __global__ void rs_plan_kernel(const float* __restrict__ bbox, const int64_t* __
     s_off += p.s_len;
     q_off += p.q_len;
   }
-  cell_start[cell_off] = (int)total_s;  // end of the last cloud's last cell
+  (void)cell_start;  // the scan over the whole counter array also writes the end of the last cloud's last cell
 }
 
 __device__ __forceinline__ int rs_find_cloud(const RsPlan* __restrict__ plan, int B, long long i, bool query) {
@@ -167,51 +195,10 @@ __global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const float* __res
   atomicAdd(&cell_count[rs_support_cell(p, s[i * 3], s[i * 3 + 1], s[i * 3 + 2])], 1);
 }
 
-// One workgroup per cloud: exclusive scan of its cells' counts (offset by the cloud's first support), cursors reset.
-__global__ __launch_bounds__(1024) void rs_scan_kernel(const RsPlan* __restrict__ plan, int* __restrict__ cell_count,
-                                                       int* __restrict__ cell_start) {
-  __shared__ int wave_tot[16];
-  __shared__ int carry_s;
-  const RsPlan p = plan[blockIdx.x];
-  const int ncell = p.dx * p.dy * p.dz;
-  int* cnt = cell_count + p.cell_off;
-  int* start = cell_start + p.cell_off;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = (int)p.s_off;
-  __syncthreads();
-  constexpr int kItems = 8;
-  for (int base = 0; base < ncell; base += 1024 * kItems) {
-    const int i0 = base + tid * kItems;
-    int v[kItems], sum = 0;
-#pragma unroll
-    for (int e = 0; e < kItems; ++e) {
-      v[e] = i0 + e < ncell ? cnt[i0 + e] : 0;
-      sum += v[e];
-    }
-    int incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int run = carry_s + incl - sum;
-    for (int q = 0; q < wave; ++q) run += wave_tot[q];
-#pragma unroll
-    for (int e = 0; e < kItems; ++e) {
-      if (i0 + e < ncell) {
-        start[i0 + e] = run;
-        cnt[i0 + e] = 0;
-      }
-      run += v[e];
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = run;
-    __syncthreads();
-  }
-}
-
+// Cell starts = one exclusive scan over the counters of ALL clouds (rocprim): the cells of cloud b follow those of cloud
+// b-1 and so do its supports, so the global running sum is the cloud's first support plus the sum within the cloud;
+// counters past the last cell are zero, so every later entry (the end marker included) reads total_s.  The fill kernel
+// counts the same counters back down to zero to hand out the slots of a cell (their order within a cell is free).
 __global__ __launch_bounds__(kRsThreads) void rs_fill_kernel(const float* __restrict__ s, const RsPlan* __restrict__ plan,
                                                              const int* __restrict__ cell_start, int* __restrict__ cursor,
                                                              float4* __restrict__ sorted, int B, long long total_s) {
@@ -220,9 +207,62 @@ __global__ __launch_bounds__(kRsThreads) void rs_fill_kernel(const float* __rest
   const RsPlan p = plan[rs_find_cloud(plan, B, i, false)];
   const float x = s[i * 3], y = s[i * 3 + 1], z = s[i * 3 + 2];
   const int c = rs_support_cell(p, x, y, z);
-  const int slot = cell_start[c] + atomicAdd(&cursor[c], 1);
+  const int slot = cell_start[c] + atomicSub(&cursor[c], 1) - 1;
   sorted[slot] = make_float4(x, y, z, __int_as_float((int)i));
 }
+
+// The cloud of query `qi` (wave-uniform), found by the whole wave at once: lane l looks at cloud l * stride, the number
+// of lanes whose cloud starts at or before qi picks the stride, a second round picks the cloud inside it.  Two dependent
+// loads at most (one for B <= 64) instead of a bisection's log2(B); empty clouds share an offset and the last one wins,
+// as in rs_find_cloud.
+__device__ __forceinline__ int rs_find_query_cloud(const RsPlan* __restrict__ plan, int B, long long qi, int lane) {
+  const int stride = (B + 63) >> 6;
+  const int i1 = lane * stride;
+  bool ok = i1 < B && plan[i1 < B ? i1 : 0].q_off <= qi;
+  int c = __builtin_popcountll(__ballot(ok)) - 1;  // >= 0: cloud 0 starts at 0
+  if (stride > 1) {
+    const int i2 = c * stride + lane;
+    const bool in = lane < stride && i2 < B;
+    ok = in && plan[in ? i2 : 0].q_off <= qi;
+    c = c * stride + __builtin_popcountll(__ballot(ok)) - 1;
+  }
+  return __builtin_amdgcn_readfirstlane(c);
+}
+
+// The 27 cells around a query are 9 runs of consecutive records (cells are x-major).  Lanes 0..8 fetch the bounds of
+// one run each (ONE memory round trip for all of them), the bounds move to scalar registers, and the wave then walks
+// the concatenation of the runs 64 candidates at a time: candidate t lies in the first run whose end exceeds t.
+struct RsRuns {
+  int beg[9], pre[10], total;
+  __device__ __forceinline__ void load(const RsPlan& p, const int* __restrict__ cell_start, float qx, float qy,
+                                       float qz, int lane) {
+    int b = 0, n = 0;
+    if (p.s_len > 0 && lane < 9) {
+      const int cx = rs_cell_coord(qx, p.ox, p.inv_h), cy = rs_cell_coord(qy, p.oy, p.inv_h),
+                cz = rs_cell_coord(qz, p.oz, p.inv_h);
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, p.dx - 1);
+      const int zz = cz - 1 + lane / 3, yy = cy - 1 + lane % 3;
+      if (x0 <= x1 && zz >= 0 && zz < p.dz && yy >= 0 && yy < p.dy) {
+        const int c0 = p.cell_off + (zz * p.dy + yy) * p.dx;
+        b = cell_start[c0 + x0];
+        n = cell_start[c0 + x1 + 1] - b;
+      }
+    }
+    pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      beg[k] = __builtin_amdgcn_readlane(b, k);
+      pre[k + 1] = pre[k] + __builtin_amdgcn_readlane(n, k);
+    }
+    total = pre[9];
+  }
+  __device__ __forceinline__ int slot(int t) const {  // 0 <= t < total
+    int j = beg[8] + (t - pre[8]);
+#pragma unroll
+    for (int k = 7; k >= 0; --k) j = t < pre[k + 1] ? beg[k] + (t - pre[k]) : j;
+    return j;
+  }
+};
 
 // ---- lane-distributed list sorted ascending by (d2, index); 64*R entries; sentinel = (+inf, INT_MAX) -----------------
 __device__ __forceinline__ int rs_shr1(int v, int fill) {  // lane l <- lane l-1, lane 0 <- fill
@@ -281,10 +321,10 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_kernel(const float* __res
                                                               int64_t* __restrict__ out, int B, long long total_q,
                                                               long long total_s, float radius, int limit) {
   const int lane = threadIdx.x & 63;
-  const long long qi = (long long)blockIdx.x * (kRsThreads / 64) + (threadIdx.x >> 6);
+  const long long qi = (long long)blockIdx.x * (kRsThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (qi >= total_q) return;
-  const RsPlan p = plan[rs_find_cloud(plan, B, qi, true)];
   const float qx = q[qi * 3], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
+  const RsPlan p = plan[rs_find_query_cloud(plan, B, qi, lane)];
   RsList<R> list;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -293,33 +333,22 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_kernel(const float* __res
   }
   float wd = INFINITY;  // current `limit`-th entry: a candidate must come before it
   int wi = INT32_MAX;
-  if (p.s_len > 0) {
-    const int cx = rs_cell_coord(qx, p.ox, p.inv_h), cy = rs_cell_coord(qy, p.oy, p.inv_h),
-              cz = rs_cell_coord(qz, p.oz, p.inv_h);
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, p.dx - 1);
-    if (x0 <= x1) {
-      for (int zz = max(cz - 1, 0); zz <= min(cz + 1, p.dz - 1); ++zz) {
-        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, p.dy - 1); ++yy) {
-          const int c0 = p.cell_off + (zz * p.dy + yy) * p.dx;
-          const int beg = cell_start[c0 + x0], end = cell_start[c0 + x1 + 1];
-          for (int j0 = beg; j0 < end; j0 += 64) {
-            const int j = j0 + lane;
-            const bool valid = j < end;
-            const float4 s = sorted[valid ? j : beg];
-            const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            const int si = __float_as_int(s.w);
-            const bool inside = valid && !(sqrtf(d2) > radius);  // radius_search.py:66 masks dist > radius
-            unsigned long long m = __ballot(inside && (d2 < wd || (d2 == wd && si < wi)));
-            while (m) {
-              const int l = __builtin_ffsll((long long)m) - 1;
-              list.insert(rs_lane(d2, l), __builtin_amdgcn_readlane(si, l), lane);
-              list.at(limit - 1, wd, wi);
-              m = __ballot(inside && (d2 < wd || (d2 == wd && si < wi))) & ~((2ull << l) - 1ull);
-            }
-          }
-        }
-      }
+  RsRuns runs;
+  runs.load(p, cell_start, qx, qy, qz, lane);
+  for (int t0 = 0; t0 < runs.total; t0 += 64) {
+    const int t = t0 + lane;
+    const bool valid = t < runs.total;
+    const float4 s = sorted[runs.slot(valid ? t : 0)];
+    const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    const int si = __float_as_int(s.w);
+    const bool inside = valid && !(sqrtf(d2) > radius);  // radius_search.py:66 masks dist > radius
+    unsigned long long m = __ballot(inside && (d2 < wd || (d2 == wd && si < wi)));
+    while (m) {
+      const int l = __builtin_ffsll((long long)m) - 1;
+      list.insert(rs_lane(d2, l), __builtin_amdgcn_readlane(si, l), lane);
+      list.at(limit - 1, wd, wi);
+      m = __ballot(inside && (d2 < wd || (d2 == wd && si < wi))) & ~((2ull << l) - 1ull);
     }
   }
   int64_t* o = out + qi * limit;
@@ -328,6 +357,134 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_kernel(const float* __res
     const int rank = 64 * r + lane;
     if (rank < limit) o[rank] = list.i[r] == INT32_MAX ? (int64_t)total_s : (int64_t)list.i[r];
   }
+}
+
+// ---- limit <= 64: batch the hits, sort them with a bitonic network, merge into the kept list ---------------------------
+// Serial insertion costs ~30 dependent instructions per hit and a realistic neighbourhood (mean count ~ limit) has
+// dozens of hits per query.  Here the hits that beat the current limit-th entry are compacted into a 64-slot per-wave
+// LDS buffer as 64-bit keys (d2 bits << 32 | index: d2 >= +0 and finite, so the unsigned order is the (d2, index)
+// order); a full buffer (and the last, partial one) is sorted DESCENDING across the lanes (21 compare-exchange steps),
+// min-ed lane by lane against the kept ASCENDING list -- the 64 smallest of the union, as a bitonic sequence -- and
+// re-sorted with 6 merge steps; a buffer of at most kRsSerialHits keys is inserted key by key instead (wave shift).
+// The result is the `limit` smallest keys, whatever order the candidates arrive in.
+constexpr unsigned long long kRsSentKey = ~0ull;
+constexpr int kRsSerialHits = 12;
+
+__device__ __forceinline__ unsigned long long rs_xor64(unsigned long long v, int j) {
+  const int lo = __shfl_xor((int)(unsigned)v, j, 64), hi = __shfl_xor((int)(v >> 32), j, 64);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long rs_cex(unsigned long long v, int j, bool keep_min) {
+  const unsigned long long o = rs_xor64(v, j);
+  return ((v < o) == keep_min) ? v : o;
+}
+__device__ __forceinline__ unsigned long long rs_sort_desc(unsigned long long v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) v = rs_cex(v, j, ((lane & j) == 0) == ((lane & k) != 0));
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long rs_merge_asc(unsigned long long v, int lane) {  // v bitonic
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) v = rs_cex(v, j, (lane & j) == 0);
+  return v;
+}
+__device__ __forceinline__ unsigned long long rs_lane64(unsigned long long v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(kRsThreads) void rs_query_sort_kernel(const float* __restrict__ q,
+                                                                   const RsPlan* __restrict__ plan,
+                                                                   const int* __restrict__ cell_start,
+                                                                   const float4* __restrict__ sorted,
+                                                                   int64_t* __restrict__ out, int B, long long total_q,
+                                                                   long long total_s, float radius, int limit) {
+  __shared__ unsigned long long hits[kRsThreads / 64][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long qi = (long long)blockIdx.x * (kRsThreads / 64) + wave;
+  if (qi >= total_q) return;
+  const float qx = q[qi * 3], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
+  const RsPlan p = plan[rs_find_query_cloud(plan, B, qi, lane)];
+  unsigned long long* buf = hits[wave];
+  unsigned long long kept = kRsSentKey;   // ascending across the lanes
+  unsigned long long worst = kRsSentKey;  // kept[limit - 1]: a candidate must come before it
+  int pending = 0;                        // keys in buf
+  auto flush = [&](int n) {
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long h = lane < n ? buf[lane] : kRsSentKey;
+    __builtin_amdgcn_wave_barrier();
+    if (n <= kRsSerialHits) {  // a handful of hits (small radius): one shifted insertion each beats the network
+      for (int e = 0; e < n; ++e) {
+        const unsigned long long key = rs_lane64(h, e);
+        const int pos = __builtin_popcountll(__ballot(kept < key));
+        const unsigned lo = (unsigned)rs_shr1((int)(unsigned)kept, 0), hi = (unsigned)rs_shr1((int)(kept >> 32), 0);
+        const unsigned long long shifted = ((unsigned long long)hi << 32) | lo;
+        kept = lane == pos ? key : (lane > pos ? shifted : kept);
+      }
+    } else {
+      h = rs_sort_desc(h, lane);
+      kept = rs_merge_asc(h < kept ? h : kept, lane);
+    }
+    worst = rs_lane64(kept, limit - 1);
+  };
+  RsRuns runs;
+  runs.load(p, cell_start, qx, qy, qz, lane);
+  for (int t0 = 0; t0 < runs.total; t0 += 64) {
+    const int t = t0 + lane;
+    const bool valid = t < runs.total;
+    const float4 s = sorted[runs.slot(valid ? t : 0)];
+    const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(s.w);
+    // radius_search.py:66 masks dist > radius; a NaN distance never enters the list
+    const bool take = valid && !(sqrtf(d2) > radius) && d2 < INFINITY && key < worst;
+    const unsigned long long m = __ballot(take);
+    if (m == 0) continue;
+    const int n = __builtin_popcountll(m);
+    const int dest = pending + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (take && dest < 64) buf[dest] = key;
+    if (pending + n >= 64) {
+      flush(64);
+      if (take && dest >= 64) buf[dest - 64] = key;
+      pending += n - 64;
+    } else {
+      pending += n;
+    }
+  }
+  if (pending > 0) flush(pending);
+  if (lane < limit) out[qi * limit + lane] = kept == kRsSentKey ? (int64_t)total_s : (int64_t)(unsigned)kept;
+}
+
+// Number of supports strictly inside `radius` of every query (ops/radius_search.py:74-107: relu(radius - d).sign().sum()
+// over the query's own cloud), on the same cell list: a wave per query, 64 candidates per step, one popcount.
+__global__ __launch_bounds__(kRsThreads) void rs_count_query_kernel(const float* __restrict__ q,
+                                                                    const RsPlan* __restrict__ plan,
+                                                                    const int* __restrict__ cell_start,
+                                                                    const float4* __restrict__ sorted,
+                                                                    int64_t* __restrict__ counts, int B, long long total_q,
+                                                                    float radius) {
+  const int lane = threadIdx.x & 63;
+  const long long qi = (long long)blockIdx.x * (kRsThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (qi >= total_q) return;
+  const float qx = q[qi * 3], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
+  const RsPlan p = plan[rs_find_query_cloud(plan, B, qi, lane)];
+  RsRuns runs;
+  runs.load(p, cell_start, qx, qy, qz, lane);
+  int cnt = 0;
+  for (int t0 = 0; t0 < runs.total; t0 += 64) {
+    const int t = t0 + lane;
+    const bool valid = t < runs.total;
+    const float4 s = sorted[runs.slot(valid ? t : 0)];
+    const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    cnt += __builtin_popcountll(__ballot(valid && (radius - sqrtf(d2) > 0.f)));  // relu(radius - d).sign()
+  }
+  if (lane == 0) counts[qi] = (int64_t)cnt;
 }
 
 }  // namespace v3d
@@ -339,13 +496,15 @@ size_t v3d_radius_search_workspace_bytes(int B, int64_t total_s) {
   return v3d::rs_carve(nullptr, B, total_s).bytes;
 }
 
-int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths,
-                               const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q,
-                               int64_t total_s, float radius, int neighbor_limit, void* workspace,
-                               size_t workspace_bytes, int device, void* stream_) {
-  using namespace v3d;
-  const char* what = "radius_search_pack_mode";
-  V3D_REQUIRE(B >= 0 && total_q >= 0 && total_s >= 0 && neighbor_limit >= 0, what, "negative dimension");
+}  // extern "C"
+
+namespace v3d {
+// neighbor_limit < 0: count mode (`out` = counts (total_q,)), else search mode (`out` = neighbor_indices)
+static int rs_run(const char* what, const float* q_points, const float* s_points, const int64_t* q_lengths,
+                  const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q, int64_t total_s,
+                  float radius, int neighbor_limit, void* workspace, size_t workspace_bytes, int device, void* stream_) {
+  const bool count_mode = neighbor_limit < 0;
+  V3D_REQUIRE(B >= 0 && total_q >= 0 && total_s >= 0, what, "negative dimension");
   if (total_q == 0 || neighbor_limit == 0) return 0;
   V3D_REQUIRE(B > 0, what, "points without clouds");
   V3D_REQUIRE(q_points && q_lengths && s_lengths && neighbor_indices && (total_s == 0 || s_points), what,
@@ -382,20 +541,36 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
       rc = (int)e;
       break;
     }
-    hipLaunchKernelGGL(rs_bbox_kernel, dim3(B), dim3(kRsThreads), 0, stream, s_points, s_lengths, ws.bbox);
+    hipLaunchKernelGGL(rs_bbox_init_kernel, dim3((unsigned)ceil_div((int64_t)B * 6, 256)), dim3(256), 0, stream, ws.bbox,
+                       B);
+    hipLaunchKernelGGL(rs_bbox_kernel, dim3(B, kRsBboxSplit), dim3(kRsThreads), 0, stream, s_points, s_lengths, ws.bbox);
     hipLaunchKernelGGL(rs_plan_kernel, dim3(1), dim3(64), 0, stream, ws.bbox, q_lengths, s_lengths, ws.plan,
                        ws.cell_start, B, radius, (long long)total_s);
+    const size_t cap = (size_t)rs_cell_capacity(B, total_s);
     if (total_s > 0) {
       const unsigned sb = (unsigned)ceil_div(total_s, kRsThreads);
       hipLaunchKernelGGL(rs_count_kernel, dim3(sb), dim3(kRsThreads), 0, stream, s_points, ws.plan, ws.cell_count, B,
                          (long long)total_s);
-      hipLaunchKernelGGL(rs_scan_kernel, dim3(B), dim3(1024), 0, stream, ws.plan, ws.cell_count, ws.cell_start);
+    }
+    size_t scan_bytes = ws.scan_bytes;
+    e = rocprim::exclusive_scan(ws.scan_tmp, scan_bytes, ws.cell_count, ws.cell_start, 0, cap, rocprim::plus<int>(),
+                                stream);
+    if (e != hipSuccess) {
+      set_last_error("%s: exclusive_scan: %s", what, hipGetErrorString(e));
+      rc = (int)e;
+      break;
+    }
+    if (total_s > 0) {
+      const unsigned sb = (unsigned)ceil_div(total_s, kRsThreads);
       hipLaunchKernelGGL(rs_fill_kernel, dim3(sb), dim3(kRsThreads), 0, stream, s_points, ws.plan, ws.cell_start,
                          ws.cell_count, ws.sorted, B, (long long)total_s);
     }
     const unsigned qb = (unsigned)ceil_div(total_q, kRsThreads / 64);
-    if (neighbor_limit <= 64)
-      hipLaunchKernelGGL(rs_query_kernel<1>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
+    if (count_mode)
+      hipLaunchKernelGGL(rs_count_query_kernel, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
+                         ws.sorted, neighbor_indices, B, (long long)total_q, radius);
+    else if (neighbor_limit <= 64)
+      hipLaunchKernelGGL(rs_query_sort_kernel, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
                          ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
                          neighbor_limit);
     else
@@ -412,6 +587,25 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
     }
   }
   return rc;
+}
+}  // namespace v3d
+
+extern "C" {
+
+int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths,
+                               const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q,
+                               int64_t total_s, float radius, int neighbor_limit, void* workspace,
+                               size_t workspace_bytes, int device, void* stream) {
+  if (neighbor_limit < 0) return v3d::invalid("radius_search_pack_mode", "negative dimension");
+  return v3d::rs_run("radius_search_pack_mode", q_points, s_points, q_lengths, s_lengths, neighbor_indices, B, total_q,
+                     total_s, radius, neighbor_limit, workspace, workspace_bytes, device, stream);
+}
+
+int v3d_radius_count_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths,
+                              const int64_t* s_lengths, int64_t* counts, int B, int64_t total_q, int64_t total_s,
+                              float radius, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  return v3d::rs_run("radius_count_pack_mode", q_points, s_points, q_lengths, s_lengths, counts, B, total_q, total_s,
+                     radius, -1, workspace, workspace_bytes, device, stream);
 }
 
 }  // extern "C"

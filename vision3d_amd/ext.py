@@ -28,6 +28,7 @@ __all__ = [
     "knn",
     "pairwise_distance",
     "radius_count",
+    "radius_count_pack",
     "knn_feat",
     "topk_merge",
     "radius_search_pack",
@@ -383,6 +384,29 @@ def radius_search_pack(q_points, s_points, q_lengths, s_lengths, neighbor_indice
         q_points.data_ptr(), s_points.data_ptr(), q_lengths.data_ptr(), s_lengths.data_ptr(),
         neighbor_indices.data_ptr(), B, M, N, float(radius), int(neighbor_limit), ws.data_ptr(), ws.numel(), dev, stream)
     _lib.check(rc, "radius_search_pack_mode")
+
+
+def radius_count_pack(q_points, s_points, q_lengths, s_lengths, counts, radius):
+    """q_points (M,3), s_points (N,3) fp32; lengths (B,) int64 on the same device; counts (M,) int64."""
+    for t, name in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"),
+                    (s_lengths, "s_lengths"), (counts, "counts")):
+        _check_cuda_contiguous(t, name)
+    _check_float(q_points, "q_points")
+    _check_float(s_points, "s_points")
+    for t, name in ((q_lengths, "q_lengths"), (s_lengths, "s_lengths"), (counts, "counts")):
+        _check_long(t, name)
+    B = q_lengths.shape[0]
+    if s_lengths.shape[0] != B:
+        raise RuntimeError("q_lengths and s_lengths must have the same number of clouds")
+    M, N = q_points.shape[0], s_points.shape[0]
+    if counts.numel() != M:
+        raise RuntimeError("radius_count_pack: counts must hold one entry per query")
+    dev, stream = _where(q_points)
+    ws = _workspace(_lib.lib().v3d_radius_search_workspace_bytes(B, N), q_points)
+    rc = _lib.lib().v3d_radius_count_pack_f32(
+        q_points.data_ptr(), s_points.data_ptr(), q_lengths.data_ptr(), s_lengths.data_ptr(), counts.data_ptr(), B, M, N,
+        float(radius), ws.data_ptr(), ws.numel(), dev, stream)
+    _lib.check(rc, "radius_count_pack_mode")
 
 
 def grid_subsample_pack(points, lengths, sampled_points, sampled_lengths, num_sampled, voxel_size):

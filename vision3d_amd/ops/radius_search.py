@@ -38,11 +38,25 @@ def padded_radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, rad
 
 
 def radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf=1e10):
-    """Number of supports strictly inside ``radius`` of each query (reference: relu(radius - d).sign().sum())."""
+    """Number of supports strictly inside ``radius`` of each query (reference: relu(radius - d).sign().sum(),
+    radius_search.py:74-107) -> (M,) int64.
+
+    fp32 3-D points count on the native cell list (no padding, no host synchronisation); anything else takes the
+    padded route.  ``inf`` is only used by that route."""
+    if q_points.dtype == torch.float32 and s_points.dtype == torch.float32 and q_points.shape[-1] == 3:
+        counts = torch.zeros((q_points.shape[0],), dtype=torch.long, device=q_points.device)
+        ext.radius_count_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.contiguous(),
+                              s_lengths.contiguous(), counts, radius)
+        return counts
+    return padded_radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf)
+
+
+def padded_radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf=1e10):
+    """The reference's formulation (radius_search.py:98-107): brute-force count over padded batches."""
     batch_q_points, batch_q_masks = pack_to_batch(q_points, q_lengths, fill_value=inf)
     batch_s_points, _ = pack_to_batch(s_points, s_lengths, fill_value=inf)
     counts = torch.zeros(batch_q_points.shape[:2], dtype=torch.long, device=q_points.device)
-    ext.radius_count(batch_q_points.contiguous(), batch_s_points.contiguous(), counts, radius)
+    ext.radius_count(batch_q_points.float().contiguous(), batch_s_points.float().contiguous(), counts, radius)
     radius_counts, _ = batch_to_pack(counts, batch_q_masks)
     return radius_counts
 
