@@ -1,18 +1,22 @@
-// radius.hip -- radius neighbours in PACK mode (variable-length clouds concatenated: points (total,3) + lengths (B,)).
+// radius.hip -- radius neighbours and radius counts in PACK mode (variable-length clouds concatenated: points (total,3) + lengths (B,)).
 // Replaces `radius_search_pack_mode` of the reference (vision3d/ops/radius_search.py:44-71): pack -> padded batch ->
 // pykeops brute-force kNN(limit) -> mask (dist > radius) -> batch -> pack, with Python loops and .item() syncs in the
 // conversions (ops/conversion.py:7-12,69-81).  Same result definition: per query, the supports of its own cloud with
 // NOT(sqrt(d2) > radius), ascending by (d2, support index), the first `limit` of them, padded with total_s.
 //
 // Design (gfx950): no padding, no host synchronisation, no brute force.  Per call:
-//   1. rs_bbox / rs_plan : bounding box per support cloud; a uniform grid per cloud with cell edge h >= 1.001 * radius
+//   1. rs_bbox / rs_plan : bounding box per support cloud (several workgroups per cloud, integer atomics on an
+//                          order-preserving encoding); a uniform grid per cloud with cell edge h >= 1.001 * radius
 //                          (enlarged until the grid has at most max(4096, 4*points) cells and <= 1024 cells per axis);
-//   2. rs_count/scan/fill: counting sort of the supports by cell (32-bit integer atomics on the cell counters only),
-//                          writing (x, y, z, index) as one 16-byte record per support in cell order;
-//   3. rs_query          : one WAVE per query.  The 27 neighbouring cells are 9 contiguous runs of records (cells are
-//                          x-major); 64 lanes test 64 candidates at once; hits are inserted into a lane-distributed
-//                          sorted list keyed by (d2, index) (whole-wave DPP shift, no LDS), bounded by the current
-//                          `limit`-th entry.  The result does not depend on the order candidates arrive in.
+//   2. rs_count/scan/fill: counting sort of the supports by cell (32-bit integer atomics on the cell counters only, one
+//                          rocprim scan over the counters of all clouds), writing (x, y, z, index) as one 16-byte
+//                          record per support in cell order;
+//   3. rs_query_*        : one WAVE per query.  The 27 neighbouring cells are 9 contiguous runs of records (cells are
+//                          x-major) whose bounds lanes 0..8 fetch in one round trip; 64 lanes test 64 candidates of the
+//                          concatenated runs at once.  limit <= 64: hits are batched in LDS as 64-bit (d2, index) keys
+//                          and merged into the kept list by a bitonic network; limit <= 128: lane-distributed sorted
+//                          list with a whole-wave DPP shift per hit.  rs_count_query: popcount of the hits.
+//                          The result does not depend on the order candidates arrive in.
 // Distances use the reference expression order (dx*dx + dy*dy) + dz*dz with one rounding per operation.
 #include <algorithm>
 #include <cstring>
