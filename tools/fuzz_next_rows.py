@@ -23,7 +23,7 @@ def table(rng, m, k, n):
 
 
 def one_case(rng, i):
-    kind = i % 10
+    kind = i % 11
     if kind == 6:  # threshold selection and global top-k on one matrix (ties on purpose: quantised scores)
         n, m = int(rng.integers(1, 1300)), int(rng.integers(1, 1300))
         score = np.round(rng.standard_normal((n, m)) * rng.choice([1, 4, 50, 1000])).astype(np.float32) / 4
@@ -85,6 +85,33 @@ def one_case(rng, i):
         got = ops.ball_query_multi(T(qs), T(sup), ks, rs)
         ok = all(np.array_equal(N_(g), oracle.ball_query(qs, sup, k, r)) for g, k, r in zip(got, ks, rs))
         return ok, f"ball_multi b{b} m{m} n{n} ks{ks} rs{rs}"
+    if kind == 10:  # pack-mode radius search (every limit class: <= 12 serial, <= 64 bitonic merge, <= 128 list) + count
+        b = int(rng.integers(1, 5))
+        ql = rng.integers(0, 400, size=b).astype(np.int64)
+        sl = rng.integers(0, 2500, size=b).astype(np.int64)
+        scale = np.float32(rng.choice([1e-2, 1, 50]))
+        off = np.float32(rng.choice([0, -3, 1e3]))
+        mode = int(rng.integers(3))
+
+        def cloud(n):
+            c = rng.random((n, 3), dtype=np.float32)
+            if mode == 1:
+                c = np.round(c * 6) / 6  # lattice: (d2, index) ties, pairs exactly at the radius
+            if mode == 2:
+                c = c * np.array([1, 1, 0.02], np.float32)  # slab: few cells along z, dense cells
+            return (c * scale + off).astype(np.float32)
+
+        q = np.concatenate([cloud(int(n)) for n in ql] + [np.zeros((0, 3), np.float32)])
+        s_ = np.concatenate([cloud(int(n)) for n in sl] + [np.zeros((0, 3), np.float32)])
+        r = float(np.float32(rng.choice([0.0, 0.04, 1 / 6, 0.3, 0.8, 3.0])) * scale)
+        lim = int(rng.choice([1, 5, 12, 13, 38, 64, 65, 100, 128]))
+        out = torch.full((q.shape[0], lim), -7, dtype=torch.long, device=DEV)
+        ext.radius_search_pack(T(q), T(s_), T(ql), T(sl), out, r, lim)
+        cnt = torch.full((q.shape[0],), -7, dtype=torch.long, device=DEV)
+        ext.radius_count_pack(T(q), T(s_), T(ql), T(sl), cnt, r)
+        ok = np.array_equal(N_(out), oracle.radius_search_pack(q, s_, ql, sl, r, lim)) and \
+            np.array_equal(N_(cnt), oracle.radius_count_pack(q, s_, ql, sl, r))
+        return ok, f"radius b{b} q{ql.tolist()} s{sl.tolist()} r{r} lim{lim} mode{mode} scale{scale} off{off}"
     if kind == 0:  # selection on a matrix
         b, n, m = int(rng.integers(1, 4)), int(rng.integers(1, 400)), int(rng.integers(1, 400))
         k = int(rng.integers(1, min(n, m, 64) + 1))
