@@ -170,7 +170,7 @@ def test_knn_points(ext, oracle_mod, dtype):
         s = pts.astype(dtype)
         q = s[:, : min(45, s.shape[1])] + (0.0 if "lattice" in name or "dup" in name else 0.001)
         q = q.astype(dtype)
-        for k in (1, 3, 16, 20, 64, 100):
+        for k in (1, 3, 16, 20, 24, 32, 63, 64, 100):  # 24..63 fp32: batched bitonic-merge kernel
             wd, wi = oracle_mod.knn_points(q, s, k)
             d = torch.zeros((q.shape[0], q.shape[1], k), dtype=T(q).dtype, device=DEV)
             idx = torch.zeros((q.shape[0], q.shape[1], k), dtype=torch.long, device=DEV)
@@ -237,6 +237,12 @@ def test_query_full_config_sizes(ext, oracle_mod):
         ext.knn_points(T(q[:8]), T(s[:8]), d, idx, 16)
         assert np.array_equal(N_(idx), wi) and np.array_equal(N_(d), wd)
         assert torch.all(d[..., 1:] >= d[..., :-1])  # sortedness
+        for k in (32, 63):  # batched bitonic-merge kernel at full cloud size
+            wd, wi = oracle_mod.knn_points(q[:4], s[:4], k)
+            d = torch.zeros((4, 1024, k), device=DEV)
+            idx = torch.zeros((4, 1024, k), dtype=torch.long, device=DEV)
+            ext.knn_points(T(q[:4]), T(s[:4]), d, idx, k)
+            assert np.array_equal(N_(idx), wi) and np.array_equal(N_(d), wd)
     finally:
         oracle_mod.set_threads(1)
 

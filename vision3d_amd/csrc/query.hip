@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "wave_sort.h"
 
 namespace v3d {
 
@@ -953,6 +954,115 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
   }
 }
 
+// fp32, k + 1 <= 64: the same search with the candidates batched.  The k+1 best so far are kept as 64-bit keys
+// (d2 bits << 32 | support index: d2 >= +0, so the unsigned order is the (distance, arrival) order of LaneList),
+// ascending across the lanes; survivors of the filter are compacted into a 64-slot LDS buffer per (wave, query) and a
+// full buffer -- or the last, partial one -- is merged by a bitonic network (wave_sort.h) instead of one whole-wave
+// insertion per survivor.  A survivor admitted against a stale bound is dropped by the merge, so the list is the same.
+template <int QPW, int TS>
+__global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const float* __restrict__ q,
+                                                                         const float* __restrict__ s,
+                                                                         float* __restrict__ out_d,
+                                                                         int64_t* __restrict__ out_i, int M, int N,
+                                                                         int k) {
+  __shared__ __align__(16) float tile[TS * 3];
+  __shared__ HeapSlot<float> heaps[kWavesPerBlock * V3D_KNN_MAX_K];
+  __shared__ wkey_t hits[kWavesPerBlock][QPW][64];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q_first = (blockIdx.x * kWavesPerBlock + wave) * QPW;
+  const float* s_cloud = s + (int64_t)b * N * 3;
+  const float sentinel = 1e10f;  // knn_points_cuda.cuh:71: nothing >= 1e10 ever enters
+  const wkey_t sent_key = (wkey_t)__float_as_uint(sentinel) << 32;  // (1e10, index 0): the reference's empty slot
+
+  float qx[QPW], qy[QPW], qz[QPW], capk[QPW];
+  wkey_t kept[QPW], worst[QPW];
+  int pending[QPW];
+#pragma unroll
+  for (int g = 0; g < QPW; ++g) {
+    const int qi = q_first + g;
+    const bool live = qi < M;
+    const float* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
+    qx[g] = qp[0];
+    qy[g] = qp[1];
+    qz[g] = qp[2];
+    kept[g] = sent_key;
+    worst[g] = live ? sent_key : 0ull;  // dead slot: nothing ever beats key 0
+    capk[g] = INFINITY;
+    pending[g] = 0;
+  }
+
+  for (int t0 = 0; t0 < N; t0 += TS) {
+    const int tcount = min(TS, N - t0);
+    __syncthreads();
+    stage_supports_aos(s_cloud, t0, tcount, tile);
+    __syncthreads();
+    if (t0 == 0 && tcount >= 256) {  // same pre-pass as knn_points_kernel: an upper bound of the (k+1)-th distance
+      float lmin[QPW];
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) lmin[g] = INFINITY;
+      for (int c0 = 0; c0 < tcount; c0 += 64) {
+        const int j = c0 + lane;
+        const bool valid = j < tcount;
+        const int jj = valid ? j : 0;
+        const float sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+#pragma unroll
+        for (int g = 0; g < QPW; ++g) {
+          const float d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
+          lmin[g] = (valid && d < lmin[g]) ? d : lmin[g];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) capk[g] = kth_smallest_upper(lmin[g], k);
+    }
+    for (int c0 = 0; c0 < tcount; c0 += 64) {
+      const int j = c0 + lane;
+      const bool valid = j < tcount;
+      const int jj = valid ? j : 0;
+      const float sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) {
+        const float d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
+        const wkey_t key = ((wkey_t)__float_as_uint(d) << 32) | (unsigned)(t0 + j);
+        const bool take = valid && key < worst[g] && d <= capk[g];  // a NaN's pattern is above the sentinel's
+        const unsigned long long m = __ballot(take);
+        if (m == 0ull) continue;
+        wkey_t* buf = hits[wave][g];
+        const int n = __builtin_popcountll(m);
+        const int dest = pending[g] + wave_prefix_count(m);
+        if (take && dest < 64) buf[dest] = key;
+        if (pending[g] + n >= 64) {
+          kept[g] = wave_merge_buffer(kept[g], buf, 64, lane);
+          worst[g] = wave_lane64(kept[g], k);
+          if (take && dest >= 64) buf[dest - 64] = key;
+          pending[g] += n - 64;
+        } else {
+          pending[g] += n;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int g = 0; g < QPW; ++g) {
+    if (q_first + g >= M) continue;
+    if (pending[g] > 0) kept[g] = wave_merge_buffer(kept[g], hits[wave][g], pending[g], lane);
+    float* od = out_d + ((int64_t)b * M + q_first + g) * k;
+    int64_t* oi = out_i + ((int64_t)b * M + q_first + g) * k;
+    const float d = __uint_as_float((unsigned)(kept[g] >> 32));
+    const float below = shr1_fill(d, -1.0f);
+    // equal real distances among ranks 0..k -> the heap's mechanics matter
+    const unsigned long long ties = __ballot(lane >= 1 && lane <= k && d == below && d < sentinel);
+    if (ties != 0ull) {
+      knn_exact_replay(s_cloud, N, k, qx[g], qy[g], qz[g], heaps + wave * V3D_KNN_MAX_K, od, oi);
+    } else if (lane < k) {
+      od[lane] = sqrtf(d);  // :90
+      oi[lane] = (int64_t)(unsigned)kept[g];
+    }
+  }
+}
+
 template <typename T>
 static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, int N, int k, int device,
                       void* stream_) {
@@ -974,6 +1084,13 @@ static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, 
   constexpr int QPW = 4;
   constexpr int TS = 1024;
   dim3 grid((unsigned)ceil_div(M, kWavesPerBlock * QPW), (unsigned)B), block(kQueryThreads);
+  if constexpr (std::is_same<T, float>::value) {
+    // batched survivors + bitonic merge: 14-25 % faster than the list from k ~ 24 up, slower below k ~ 12
+    if (k >= 24 && k + 1 <= 64 && getenv("V3D_KNN_LIST") == nullptr) {
+      hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
+      return launch_status(what);
+    }
+  }
   if (k + 1 <= 64)  // the list holds the k+1 best: one or two entries per lane
     hipLaunchKernelGGL((knn_points_kernel<T, 1, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
   else

@@ -24,6 +24,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "wave_sort.h"
 
 namespace v3d {
 
@@ -369,37 +370,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_kernel(const float* __res
 // LDS buffer as 64-bit keys (d2 bits << 32 | index: d2 >= +0 and finite, so the unsigned order is the (d2, index)
 // order); a full buffer (and the last, partial one) is sorted DESCENDING across the lanes (21 compare-exchange steps),
 // min-ed lane by lane against the kept ASCENDING list -- the 64 smallest of the union, as a bitonic sequence -- and
-// re-sorted with 6 merge steps; a buffer of at most kRsSerialHits keys is inserted key by key instead (wave shift).
+// re-sorted with 6 merge steps (wave_sort.h); a buffer of at most kWaveSerialKeys keys is inserted key by key instead (wave shift).
 // The result is the `limit` smallest keys, whatever order the candidates arrive in.
-constexpr unsigned long long kRsSentKey = ~0ull;
-constexpr int kRsSerialHits = 12;
-
-__device__ __forceinline__ unsigned long long rs_xor64(unsigned long long v, int j) {
-  const int lo = __shfl_xor((int)(unsigned)v, j, 64), hi = __shfl_xor((int)(v >> 32), j, 64);
-  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
-}
-__device__ __forceinline__ unsigned long long rs_cex(unsigned long long v, int j, bool keep_min) {
-  const unsigned long long o = rs_xor64(v, j);
-  return ((v < o) == keep_min) ? v : o;
-}
-__device__ __forceinline__ unsigned long long rs_sort_desc(unsigned long long v, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) v = rs_cex(v, j, ((lane & j) == 0) == ((lane & k) != 0));
-  }
-  return v;
-}
-__device__ __forceinline__ unsigned long long rs_merge_asc(unsigned long long v, int lane) {  // v bitonic
-#pragma unroll
-  for (int j = 32; j > 0; j >>= 1) v = rs_cex(v, j, (lane & j) == 0);
-  return v;
-}
-__device__ __forceinline__ unsigned long long rs_lane64(unsigned long long v, int l) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l);
-  return ((unsigned long long)hi << 32) | lo;
-}
+constexpr wkey_t kRsSentKey = kWaveKeyMax;
 
 __global__ __launch_bounds__(kRsThreads) void rs_query_sort_kernel(const float* __restrict__ q,
                                                                    const RsPlan* __restrict__ plan,
@@ -419,22 +392,8 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_sort_kernel(const float* 
   unsigned long long worst = kRsSentKey;  // kept[limit - 1]: a candidate must come before it
   int pending = 0;                        // keys in buf
   auto flush = [&](int n) {
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long h = lane < n ? buf[lane] : kRsSentKey;
-    __builtin_amdgcn_wave_barrier();
-    if (n <= kRsSerialHits) {  // a handful of hits (small radius): one shifted insertion each beats the network
-      for (int e = 0; e < n; ++e) {
-        const unsigned long long key = rs_lane64(h, e);
-        const int pos = __builtin_popcountll(__ballot(kept < key));
-        const unsigned lo = (unsigned)rs_shr1((int)(unsigned)kept, 0), hi = (unsigned)rs_shr1((int)(kept >> 32), 0);
-        const unsigned long long shifted = ((unsigned long long)hi << 32) | lo;
-        kept = lane == pos ? key : (lane > pos ? shifted : kept);
-      }
-    } else {
-      h = rs_sort_desc(h, lane);
-      kept = rs_merge_asc(h < kept ? h : kept, lane);
-    }
-    worst = rs_lane64(kept, limit - 1);
+    kept = wave_merge_buffer(kept, buf, n, lane);
+    worst = wave_lane64(kept, limit - 1);
   };
   RsRuns runs;
   runs.load(p, cell_start, qx, qy, qz, lane);
@@ -450,7 +409,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_sort_kernel(const float* 
     const unsigned long long m = __ballot(take);
     if (m == 0) continue;
     const int n = __builtin_popcountll(m);
-    const int dest = pending + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    const int dest = pending + wave_prefix_count(m);
     if (take && dest < 64) buf[dest] = key;
     if (pending + n >= 64) {
       flush(64);
