@@ -391,8 +391,10 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_sort_kernel(const float* 
   unsigned long long kept = kRsSentKey;   // ascending across the lanes
   unsigned long long worst = kRsSentKey;  // kept[limit - 1]: a candidate must come before it
   int pending = 0;                        // keys in buf
+  bool empty = true;  // nothing kept yet: the first merge is a plain sort
   auto flush = [&](int n) {
-    kept = wave_merge_buffer(kept, buf, n, lane);
+    kept = wave_merge_buffer(kept, buf, n, lane, empty);
+    empty = false;
     worst = wave_lane64(kept, limit - 1);
   };
   RsRuns runs;

@@ -19,15 +19,16 @@ __device__ __forceinline__ wkey_t wave_cex(wkey_t v, int j, bool keep_min) {
   const wkey_t o = wave_xor64(v, j);
   return ((v < o) == keep_min) ? v : o;
 }
-// Full bitonic sort, DESCENDING across the lanes (21 compare-exchange steps).
-__device__ __forceinline__ wkey_t wave_sort_desc(wkey_t v, int lane) {
+// Full bitonic sort across the lanes (21 compare-exchange steps), descending or ascending (`desc` wave-uniform).
+__device__ __forceinline__ wkey_t wave_sort(wkey_t v, int lane, bool desc) {
 #pragma unroll
   for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) v = wave_cex(v, j, ((lane & j) == 0) == ((lane & k) != 0));
+    for (int j = k >> 1; j > 0; j >>= 1) v = wave_cex(v, j, ((lane & j) == 0) == (((lane & k) != 0) == desc));
   }
   return v;
 }
+__device__ __forceinline__ wkey_t wave_sort_desc(wkey_t v, int lane) { return wave_sort(v, lane, true); }
 // v bitonic across the lanes -> ascending (6 steps).
 __device__ __forceinline__ wkey_t wave_merge_asc(wkey_t v, int lane) {
 #pragma unroll
@@ -51,15 +52,17 @@ __device__ __forceinline__ wkey_t wave_insert_asc(wkey_t kept, wkey_t key, int l
 }
 // Merge the first n (wave-uniform, 1..64) keys of a per-wave LDS buffer into `kept` (ascending, 64 smallest survive).
 constexpr int kWaveSerialKeys = 12;  // up to here one shifted insertion per key beats the network
-__device__ __forceinline__ wkey_t wave_merge_buffer(wkey_t kept, const wkey_t* buf, int n, int lane) {
+// `kept_empty` (wave-uniform): every entry of `kept` is kWaveKeyMax, so sorting the buffer ascending is the whole merge.
+__device__ __forceinline__ wkey_t wave_merge_buffer(wkey_t kept, const wkey_t* buf, int n, int lane,
+                                                    bool kept_empty = false) {
   __builtin_amdgcn_wave_barrier();
   wkey_t h = lane < n ? buf[lane] : kWaveKeyMax;
   __builtin_amdgcn_wave_barrier();
   if (n <= kWaveSerialKeys) {
     for (int e = 0; e < n; ++e) kept = wave_insert_asc(kept, wave_lane64(h, e), lane);
   } else {
-    h = wave_sort_desc(h, lane);
-    kept = wave_merge_asc(h < kept ? h : kept, lane);
+    h = wave_sort(h, lane, !kept_empty);
+    kept = kept_empty ? h : wave_merge_asc(h < kept ? h : kept, lane);
   }
   return kept;
 }
