@@ -33,7 +33,15 @@ __device__ __forceinline__ int gs_voxel(float p, float scale) {
   return (int)floorf(scale > 0.f ? p * scale : p / -scale);
 }
 
-// One workgroup per cloud: its first point and its minimum voxel (grid_subsample.py:75).
+constexpr int kGsMinSplit = 16;  // workgroups per cloud in the minimum-voxel pass
+
+__global__ void gs_minvox_init_kernel(int* __restrict__ minv, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * 3) minv[i] = INT32_MAX;
+}
+
+// kGsMinSplit workgroups per cloud: its first point and its minimum voxel (grid_subsample.py:75), combined with
+// integer atomics (exact, order-free).
 __global__ __launch_bounds__(kGsThreads) void gs_minvox_kernel(const float* __restrict__ pts,
                                                                const int64_t* __restrict__ lengths,
                                                                long long* __restrict__ offsets, int* __restrict__ minv,
@@ -43,8 +51,13 @@ __global__ __launch_bounds__(kGsThreads) void gs_minvox_kernel(const float* __re
   long long off = 0;
   for (int i = 0; i < b; ++i) off += lengths[i];
   const long long n = lengths[b];
+  if (tid == 0 && blockIdx.y == 0) {
+    offsets[b] = off;
+    if (b == B - 1) offsets[B] = off + n;
+  }
+  if ((long long)blockIdx.y * kGsThreads >= n) return;
   int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
-  for (long long i = tid; i < n; i += kGsThreads) {
+  for (long long i = (long long)blockIdx.y * kGsThreads + tid; i < n; i += (long long)kGsThreads * kGsMinSplit) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) lo[a] = min(lo[a], gs_voxel(pts[(off + i) * 3 + a], inv));
   }
@@ -57,11 +70,7 @@ __global__ __launch_bounds__(kGsThreads) void gs_minvox_kernel(const float* __re
   if (tid < 3) {
     int v = red[tid][0];
     for (int w = 1; w < kGsThreads / 64; ++w) v = min(v, red[tid][w]);
-    minv[b * 3 + tid] = v;
-  }
-  if (tid == 0) {
-    offsets[b] = off;
-    if (b == B - 1) offsets[B] = off + n;
+    atomicMin(&minv[b * 3 + tid], v);
   }
 }
 
@@ -244,7 +253,9 @@ static int grid_reduce(const char* what, const float* points, const int64_t* len
       break;
     }
     const unsigned blocks = (unsigned)ceil_div(total, kGsThreads);
-    hipLaunchKernelGGL(gs_minvox_kernel, dim3(B), dim3(kGsThreads), 0, stream, points, lengths, offsets, minv, B, inv);
+    hipLaunchKernelGGL(gs_minvox_init_kernel, dim3((unsigned)ceil_div((int64_t)B * 3, 256)), dim3(256), 0, stream, minv, B);
+    hipLaunchKernelGGL(gs_minvox_kernel, dim3(B, kGsMinSplit), dim3(kGsThreads), 0, stream, points, lengths, offsets, minv,
+                       B, inv);
     hipLaunchKernelGGL(gs_keys_kernel, dim3(blocks), dim3(kGsThreads), 0, stream, points, offsets, minv, k0, v0, error,
                        B, (long long)total, inv);
     e = rocprim::radix_sort_pairs(tmp, sort_bytes, k0, k1, v0, v1, n, 0, end_bit, stream);
