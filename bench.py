@@ -14,7 +14,7 @@ clouds shard by batch (one process per GPU, no data-path collective), so scaling
 own B=32 batch; the only collectives are the timing barrier and a MAX all-reduce of the elapsed time.
 
 `roofline` describes the dominant HBM kernel (group_gather forward, k=128, C=64): algorithmic bytes per launch /
-its average duration measured with HIP events inside the timed steps.  `cpu_baseline` is the CPU oracle (a port of
+its average duration measured with HIP events inside the timed steps (every EVENT_EVERY-th step carries the events).  `cpu_baseline` is the CPU oracle (a port of
 the reference kernels' semantics, OpenMP over clouds/queries) timed on this host on the same workload.
 """
 import argparse
@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achiev
 B, N, M, C_FEAT, C_INTERP = 32, 4096, 1024, 64, 128
 SCALES = ((0.1, 16), (0.2, 32), (0.4, 128))
 QUERIES_PER_STEP = len(SCALES) * B * M + B * N  # ball queries + three_nn queries
+EVENT_EVERY = 5  # timed steps whose launches carry HIP events (per-operator durations, roofline)
 
 
 def make_inputs(seed, device):
@@ -198,21 +199,25 @@ def main():
             steps.append(Step(inp, device, fused_msg=args.fused_msg))
     torch.cuda.synchronize()
 
-    def run_steps(n):
+    timers = []
+
+    def run_steps(n, timed=False):
+        # Per-operator HIP events go around every launch of every EVENT_EVERY-th timed step (alternating streams): an
+        # event pair is a barrier packet either side of the kernel, and on every step they cost 5-8 % of the step time
+        # (tools/host_overhead.py), which is not the operators' time.
         for i in range(n):
+            st = steps[i % nstream]
+            st.timers = timers if (timed and i % EVENT_EVERY == 0) else None
             with torch.cuda.stream(streams[i % nstream]):
-                steps[i % nstream].run()
+                st.run()
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    timers = []
-    for st in steps:
-        st.timers = timers
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, timed=True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -258,7 +263,8 @@ def main():
             "fps_points_per_sec": B * N * world / (per_op_ms["fps"] * 1e-3),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": alg[dom], "avg_ms": per_op_ms[dom]},
+                         "algorithmic_bytes": alg[dom], "avg_ms": per_op_ms[dom],
+                         "launches_timed": len(per_op[dom])},
             "per_op_ms": per_op_ms,
             "per_op_alg_GBs": {k: alg[k] / (per_op_ms[k] * 1e-3) / 1e9 for k in alg if k in per_op_ms},
         }
