@@ -694,6 +694,35 @@ def test_radius_count_pack_nonfinite_and_refusals(ext, oracle_mod):
         ext.radius_count_pack(T(q), T(s), T(ql), T(sl), out[:10], 0.2)
 
 
+def test_radius_pack_c_abi_null_workspace_and_bad_workspace(ext, oracle_mod):
+    """Straight through the C ABI: workspace NULL (the library allocates stream-ordered scratch) gives the same tables
+    as a caller-provided workspace; a workspace that is too small is refused with V3D_ERR_WORKSPACE."""
+    from vision3d_amd import _lib
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(65)
+    q, s, ql, sl = _pack_clouds(rng, (300, 150), (2000, 900))
+    tq, ts, tql, tsl = T(q), T(s), T(ql), T(sl)
+    limit, r = 40, 0.12
+    out = torch.full((450, limit), -7, dtype=torch.long, device=DEV)
+    cnt = torch.full((450,), -7, dtype=torch.long, device=DEV)
+    dev = torch.cuda.current_device()
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = lib.v3d_radius_search_pack_f32(tq.data_ptr(), ts.data_ptr(), tql.data_ptr(), tsl.data_ptr(), out.data_ptr(), 2,
+                                        450, 2900, r, limit, None, 0, dev, stream)
+    assert rc == 0, lib.v3d_last_error_string()
+    rc = lib.v3d_radius_count_pack_f32(tq.data_ptr(), ts.data_ptr(), tql.data_ptr(), tsl.data_ptr(), cnt.data_ptr(), 2,
+                                       450, 2900, r, None, 0, dev, stream)
+    assert rc == 0, lib.v3d_last_error_string()
+    torch.cuda.synchronize()
+    assert np.array_equal(N_(out), oracle_mod.radius_search_pack(q, s, ql, sl, r, limit))
+    assert np.array_equal(N_(cnt), oracle_mod.radius_count_pack(q, s, ql, sl, r))
+    small = torch.empty((1024,), dtype=torch.uint8, device=DEV)
+    rc = lib.v3d_radius_count_pack_f32(tq.data_ptr(), ts.data_ptr(), tql.data_ptr(), tsl.data_ptr(), cnt.data_ptr(), 2,
+                                       450, 2900, r, small.data_ptr(), small.numel(), dev, stream)
+    assert rc != 0 and lib.v3d_error_name(rc).decode() == "V3D_ERR_WORKSPACE"
+
+
 def test_radius_search_pack_mode_op_matches_padded_route(ext, oracle_mod):
     """ops.radius_search_pack_mode (native) == the reference's formulation (kNN over padded batches + mask) on
     tie-free inputs, and queries outside the supports' bounding box are handled."""
