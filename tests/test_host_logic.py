@@ -163,6 +163,9 @@ def test_next_row_ops_signatures_and_no_cpu_path():
         "knn_interpolate": ["q_points", "s_points", "s_feats", "k", "eps", "distance_limit"],
         "get_point_to_node_indices": ["points", "nodes", "return_counts"],
         "naive_radius_search_pack_mode": ["q_points", "s_points", "q_lengths", "s_lengths", "radius", "neighbor_limit"],
+        # ops/radius_search.py:44, :84
+        "radius_search_pack_mode": ["q_points", "s_points", "q_lengths", "s_lengths", "radius", "neighbor_limit", "inf"],
+        "radius_count_pack_mode": ["q_points", "s_points", "q_lengths", "s_lengths", "radius", "inf"],
     }
     for name, args in expect.items():
         assert list(inspect.signature(getattr(ops, name)).parameters) == args, name
@@ -181,6 +184,10 @@ def test_next_row_ops_signatures_and_no_cpu_path():
                  lambda: ops.knn_interpolate_pack_mode(torch.zeros(3, 3), torch.zeros(5, 3), f, t),
                  lambda: ops.knn_interpolate(torch.zeros(3, 3), torch.zeros(5, 3), f),
                  lambda: ops.get_point_to_node_indices(torch.zeros(5, 3), torch.zeros(2, 3)),
+                 lambda: ops.radius_count_pack_mode(torch.zeros(5, 3), torch.zeros(5, 3), torch.tensor([5]),
+                                                    torch.tensor([5]), 0.1),
+                 lambda: ops.radius_search_pack_mode(torch.zeros(5, 3), torch.zeros(5, 3), torch.tensor([5]),
+                                                     torch.tensor([5]), 0.1, 4),
                  lambda: ops.sa_group(torch.zeros(1, 3, 2), torch.zeros(1, 3, 5), None, torch.zeros(1, 2, 2, dtype=torch.long)),
                  lambda: ops.edge_group(torch.zeros(1, 4, 2), torch.zeros(1, 4, 5), torch.zeros(1, 2, 2, dtype=torch.long)),
                  lambda: ops.kpconv_gather(torch.zeros(3, 3), torch.zeros(5, 3), f, t, torch.zeros(15, 3), 0.1)):
