@@ -23,7 +23,7 @@ def table(rng, m, k, n):
 
 
 def one_case(rng, i):
-    kind = i % 11
+    kind = i % 12
     if kind == 6:  # threshold selection and global top-k on one matrix (ties on purpose: quantised scores)
         n, m = int(rng.integers(1, 1300)), int(rng.integers(1, 1300))
         score = np.round(rng.standard_normal((n, m)) * rng.choice([1, 4, 50, 1000])).astype(np.float32) / 4
@@ -85,6 +85,20 @@ def one_case(rng, i):
         got = ops.ball_query_multi(T(qs), T(sup), ks, rs)
         ok = all(np.array_equal(N_(g), oracle.ball_query(qs, sup, k, r)) for g, k, r in zip(got, ks, rs))
         return ok, f"ball_multi b{b} m{m} n{n} ks{ks} rs{rs}"
+    if kind == 11:  # knn_points: list kernel (k < 24, k >= 64) and bitonic-merge kernel (24 <= k <= 63), ties on lattices
+        b, m, n = int(rng.integers(1, 4)), int(rng.integers(1, 200)), int(rng.integers(1, 3000))
+        sup = rng.random((b, n, 3), dtype=np.float32) * np.float32(rng.choice([1e-2, 1, 100]))
+        if rng.integers(3) == 0:
+            sup = (np.round(sup / max(float(sup.max()), 1e-6) * 7) * np.float32(0.125)).astype(np.float32)
+        qs = sup[:, rng.integers(0, n, size=m)] + (rng.random((b, m, 3), dtype=np.float32) < 0.5) * np.float32(0.01)
+        qs = qs.astype(np.float32)
+        k = int(rng.choice([1, 8, 23, 24, 25, 32, 40, 63, 64, 100]))
+        wd, wi = oracle.knn_points(qs, sup, k)
+        d = torch.zeros((b, m, k), device=DEV)
+        idx = torch.zeros((b, m, k), dtype=torch.long, device=DEV)
+        ext.knn_points(T(qs), T(sup), d, idx, k)
+        ok = np.array_equal(N_(idx), wi) and np.array_equal(N_(d), wd)
+        return ok, f"knn_points b{b} m{m} n{n} k{k}"
     if kind == 10:  # pack-mode radius search (every limit class: <= 12 serial, <= 64 bitonic merge, <= 128 list) + count
         b = int(rng.integers(1, 5))
         ql = rng.integers(0, 400, size=b).astype(np.int64)
