@@ -52,7 +52,8 @@ def radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf
 
 
 def padded_radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf=1e10):
-    """The reference's formulation (radius_search.py:98-107): brute-force count over padded batches."""
+    """The reference's formulation (radius_search.py:98-107): brute-force count over padded batches.  The count kernel
+    is fp32: other floating dtypes are converted first (a pair within fp32 rounding of the radius may count differently)."""
     batch_q_points, batch_q_masks = pack_to_batch(q_points, q_lengths, fill_value=inf)
     batch_s_points, _ = pack_to_batch(s_points, s_lengths, fill_value=inf)
     counts = torch.zeros(batch_q_points.shape[:2], dtype=torch.long, device=q_points.device)
