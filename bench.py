@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path of BASELINE.json config[1] on N GPUs of one node.
+"""bench.py -- the hot path of BASELINE.json config[1] on N GPUs of one node, plus one short line per other config.
 
-Workload "pointnet2_msg_fp_s3dis" (SURVEY.md 8d, C2), one STEP = one pass over one batch of B=32 synthetic
+usage: python bench.py --gpus N --steps K --warmup W [--workload c2|c5_refset]
+  Under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set, e.g. torch.distributed.run) this process IS one rank.  Without
+  one and with --gpus N > 1 this process is only a parent: it starts N rank processes itself (before anything touches
+  the GPU), relays rank 0's JSON line and exits with the worst child code.
+
+Workload "pointnet2_msg_fp_s3dis" (default), one STEP = one pass over one batch of B=32 synthetic
 S3DIS-sized blocks of N=4096 points, inputs already resident in HBM, outputs pre-allocated:
     FPS 4096 -> 1024 | gather centroids | for (r,k) in (0.1,16),(0.2,32),(0.4,128): ball_query,
     group_gather(xyz, 3 ch), group_gather(features, 64 ch) | three_nn 4096 <- 1024 | interpolation weights
@@ -11,34 +16,75 @@ Every operator call goes through vision3d_amd.ext -> the C ABI -> hand-written g
 Metric (BASELINE.json): neighbor queries/sec = (3*B*M ball queries + B*Q three_nn queries) / step time, whole job
 over all ranks; FPS points/sec and per-operator timings ride along in the same JSON line.  Multi-GPU: independent
 clouds shard by batch (one process per GPU, no data-path collective), so scaling is "weak": every rank runs its
-own B=32 batch; the only collectives are the timing barrier and a MAX all-reduce of the elapsed time.
+own B=32 batch; the only collectives around the timed region are the barrier and a MAX all-reduce of the elapsed time.
 
-`roofline` describes the dominant HBM kernel (group_gather forward, k=128, C=64): algorithmic bytes per launch /
-its average duration measured with HIP events inside the timed steps (every EVENT_EVERY-th step carries the events).  `cpu_baseline` is the CPU oracle (a port of
-the reference kernels' semantics, OpenMP over clouds/queries) timed on this host on the same workload.
+`roofline` describes the dominant HBM kernel (group_gather forward, k=128, C=64): algorithmic bytes per launch / its
+average duration from a HIP event pair around that launch on EVERY timed step (the other operators carry events on
+every EVENT_EVERY-th step only).  `cpu_baseline` = the CPU oracle (port of the reference kernels' semantics, OpenMP) on
+the same workload; `cpu_baseline_reference` = the reference's own CPU path for the query operators (scipy cKDTree as
+vision3d/array_ops/{ball_query,knn}.py call it) on the same inputs.
+
+`per_config` (after the timed region, excluded from ms_per_step) carries the other BASELINE configs: C1 step, C3 feature
+kNN, C4 radius search + grid subsampling, C5 one-GPU shard, and -- when N > 1 -- C5 with the reference set sharded over
+the ranks: partial top-k per rank, ONE all-gather over RCCL, merge, compared on the device with the single-GPU result.
+`--workload c5_refset` makes that sharded search the timed step (scaling "strong": 100k queries in total).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (no TF32 on gfx950)
 
 B, N, M, C_FEAT, C_INTERP = 32, 4096, 1024, 64, 128
 SCALES = ((0.1, 16), (0.2, 32), (0.4, 128))
 QUERIES_PER_STEP = len(SCALES) * B * M + B * N  # ball queries + three_nn queries
-EVENT_EVERY = 5  # timed steps whose launches carry HIP events (per-operator durations, roofline)
+EVENT_EVERY = 5  # timed steps whose launches ALL carry HIP events (per-operator durations)
+DOMINANT = "group_gather_feat_k128"  # carries an event pair on every timed step (roofline)
+C5_ROWS, C5_DIM = 100000, 256
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Parent mode: start one process per GPU.  Nothing here may initialise the GPU (no torch.cuda call that creates a
+# context; the children are fresh processes, never an exec of a process that touched the card).
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    world = args.gpus
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if rank == 0 else subprocess.DEVNULL  # rank 0 prints the JSON line; stderr of every rank is kept
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        worst = worst or rc
+    return worst
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def make_inputs(seed, device):
+    import torch
+
     g = torch.Generator().manual_seed(seed)
     pts = torch.rand((B, N, 3), generator=g)  # ~U[0,1)^3: a 1 m block
     feats = torch.randn((B, C_FEAT, N), generator=g)
@@ -51,10 +97,12 @@ class Step:
     """Pre-allocated buffers + the operator sequence; `timers` collects (name, start_event, end_event)."""
 
     def __init__(self, inp, device, fused_msg=False):
+        import torch
+
         from vision3d_amd import ext
 
+        self.torch = torch
         self.fused_msg = fused_msg
-
         self.ext = ext
         self.inp = inp
         dev = device
@@ -70,17 +118,22 @@ class Step:
         self.tnn_i = torch.zeros((B, N, 3), dtype=torch.long, device=dev)
         self.interp = torch.empty((B, C_INTERP, N), device=dev)
         self.sgrad = torch.empty((B, C_INTERP, M), device=dev)
-        self.timers = None
+        self.timers = None  # list: every launch carries events
+        self.dom_timers = None  # list: only the dominant launch carries events
 
     def _timed(self, name, fn):
-        if self.timers is None:
+        sink = self.timers
+        if sink is None and name == DOMINANT:
+            sink = self.dom_timers
+        if sink is None:
             fn()
             return
+        torch = self.torch
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.timers.append((name, s, e))
+        sink.append((name, s, e))
 
     def run(self):
         ext, inp = self.ext, self.inp
@@ -124,17 +177,28 @@ def algorithmic_bytes():
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N = 1 only).  The only place bench.py touches oracle/.
+# ----------------------------------------------------------------------------------------------------------------------
+def _cpu_inputs(seed):
+    import numpy as np
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand((B, N, 3), generator=g).numpy()
+    feats = torch.randn((B, C_FEAT, N), generator=g).numpy()
+    sfeats = torch.randn((B, C_INTERP, M), generator=g).numpy()
+    grad = torch.randn((B, C_INTERP, N), generator=g).numpy()
+    return pts, feats, sfeats, grad, np
+
+
 def cpu_baseline(seed, budget_s=12.0):
     """The same step on the CPU oracle (port of the reference kernel semantics), all host cores."""
     import oracle
 
     cores = min(oracle.max_threads(), os.cpu_count() or 1)
     oracle.set_threads(cores)
-    g = torch.Generator().manual_seed(seed)
-    pts = torch.rand((B, N, 3), generator=g).numpy()
-    feats = torch.randn((B, C_FEAT, N), generator=g).numpy()
-    sfeats = torch.randn((B, C_INTERP, M), generator=g).numpy()
-    grad = torch.randn((B, C_INTERP, N), generator=g).numpy()
+    pts, feats, sfeats, grad, np = _cpu_inputs(seed)
     pts_cf = np.ascontiguousarray(np.swapaxes(pts, 1, 2))
     reps, t0 = 0, time.perf_counter()
     while True:
@@ -161,32 +225,267 @@ def cpu_baseline(seed, budget_s=12.0):
         "kind": "port",
         "sample": f"{reps} full step(s) of the same B={B},N={N} workload on the CPU oracle "
                   f"(oracle/v3d_oracle.c, OpenMP x{cores}), {el:.1f} s",
+    }, q
+
+
+def cpu_baseline_reference(seed, q, budget_s=10.0):
+    """The reference's CPU path for the QUERY operators of the step, as vision3d/array_ops/ball_query.py:8-9
+    (cKDTree(s).query_ball_point(q, r)) and array_ops/knn.py:11-12 (cKDTree(s).query(q, k)) run them, all host cores
+    (workers=-1), tree construction included as in the reference.  No gathers / interpolation: array_ops has none."""
+    import warnings
+
+    from scipy.spatial import cKDTree
+
+    pts = _cpu_inputs(seed)[0]
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
+    done, t0 = 0, time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for b in range(B):  # bounded sample: as many whole clouds as fit the budget
+            tree = cKDTree(pts[b])
+            for r, _ in SCALES:
+                tree.query_ball_point(q[b], r, workers=-1)
+            cKDTree(q[b]).query(pts[b], k=3, workers=-1)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    el = time.perf_counter() - t0
+    return {
+        "value": (len(SCALES) * M + N) * done / el,
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": "reference CPU path restated on scipy (array_ops/ball_query.py:8-9, array_ops/knn.py:11-12)",
+        "sample": f"{done} of the {B} clouds of the same inputs: 3 query_ball_point scales + k=3 query per cloud, "
+                  f"workers=-1, {el:.1f} s",
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="batches in flight (one HIP stream each)")
-    ap.add_argument("--fused-msg", action="store_true",
-                    help="one ext.ball_query_multi launch for the three MSG scales instead of the reference's three "
-                         "ball_query calls (same outputs; off by default: the default step is the reference's call pattern)")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------------------------------
+# The other BASELINE configs: short loops after the timed region.
+# ----------------------------------------------------------------------------------------------------------------------
+def _loop_ms(torch, fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def c5_features(torch, device, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.nn.functional.normalize(torch.randn((C5_ROWS, C5_DIM), generator=g), dim=1).to(device)
+    y = torch.nn.functional.normalize(torch.randn((C5_ROWS, C5_DIM), generator=g), dim=1).to(device)
+    return x, y
+
+
+def per_config_single(torch, device):
+    """C1, C3, C4 and the C5 one-GPU shard on this rank's GPU (N = 1 run)."""
+    from vision3d_amd import ext
+
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # ---- C1: PointNet++ SSG set abstraction, B=16, N=1024 unit-sphere cloud, FPS -> 512, r=0.2 k=32, C=64
+    b1, n1, m1, k1, c1 = 16, 1024, 512, 32, 64
+    p = torch.randn((b1, n1, 3), generator=g)
+    p = p - p.mean(dim=1, keepdim=True)
+    p = (p / p.norm(dim=2).amax(dim=1).view(b1, 1, 1)).to(device)
+    p_cf = p.transpose(1, 2).contiguous()
+    f = torch.randn((b1, c1, n1), generator=g).to(device)
+    dist = torch.empty((b1, n1), device=device)
+    idx = torch.zeros((b1, m1), dtype=torch.long, device=device)
+    q_cf = torch.empty((b1, 3, m1), device=device)
+    bi = torch.zeros((b1, m1, k1), dtype=torch.long, device=device)
+    gx = torch.empty((b1, 3, m1, k1), device=device)
+    gf = torch.empty((b1, c1, m1, k1), device=device)
+
+    def c1_step():
+        dist.fill_(1e10)
+        ext.furthest_point_sample(p, dist, idx, m1)
+        ext.gather_forward(p_cf, idx, q_cf)
+        q = q_cf.transpose(1, 2).contiguous()
+        bi.zero_()
+        ext.ball_query(q, p, bi, 0.2, k1)
+        ext.group_gather_forward(p_cf, bi, gx)
+        ext.group_gather_forward(f, bi, gf)
+
+    def c1_fps():
+        dist.fill_(1e10)
+        ext.furthest_point_sample(p, dist, idx, m1)
+
+    ms = _loop_ms(torch, c1_step, 50)
+    ms_fps = _loop_ms(torch, c1_fps, 50)
+    out["c1_pointnet2_ssg"] = {"workload": "B16 N1024 FPS->512, ball_query r0.2 k32, group_gather C64 (+xyz)",
+                               "ms_per_step": ms, "queries_per_sec": b1 * m1 / (ms * 1e-3),
+                               "fps_points_per_sec": b1 * n1 / (ms_fps * 1e-3), "fps_ms": ms_fps}
+    # ---- C3: DGCNN feature-space kNN, B=32, N=1024, C=64, k=20 (self included)
+    b3, n3, c3, k3 = 32, 1024, 64, 20
+    x = torch.randn((b3, n3, c3), generator=g).to(device)
+    d = torch.empty((b3, n3, k3), device=device)
+    i = torch.empty((b3, n3, k3), dtype=torch.long, device=device)
+    ms = _loop_ms(torch, lambda: ext.knn_feat(x, x, d, i, k3), 50)
+    tf = 2.0 * b3 * n3 * n3 * c3 / (ms * 1e-3) / 1e12
+    out["c3_dgcnn_feature_knn"] = {"workload": "B32 N1024 C64 k20, fused fp32-MFMA distance + top-k", "ms": ms,
+                                   "queries_per_sec": b3 * n3 / (ms * 1e-3), "tflops": tf,
+                                   "mfma_frac": tf / MFMA_F32_PEAK_TFLOPS}
+    # ---- C4: 16 clouds x 30,000 points in a 3 x 3 x 2.5 m box: radius search (r 0.0625, limit 38) + grid subsampling
+    nc, n4, lim = 16, 30000, 38
+    pts = (torch.rand((nc * n4, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(device)
+    lengths = torch.full((nc,), n4, dtype=torch.long, device=device)
+    table = torch.empty((nc * n4, lim), dtype=torch.long, device=device)
+    o, ol = torch.empty_like(pts), torch.empty_like(lengths)
+    num = torch.zeros((), dtype=torch.long, device=device)
+    ms_r = _loop_ms(torch, lambda: ext.radius_search_pack(pts, pts, lengths, lengths, table, 0.0625, lim), 30)
+    ms_g = _loop_ms(torch, lambda: ext.grid_subsample_pack(pts, lengths, o, ol, num, 0.025), 30)
+    out["c4_kpconv_pyramid_stage"] = {"workload": "16 clouds x 30000 pts, radius 0.0625 limit 38, voxel 0.025",
+                                      "radius_search_ms": ms_r, "radius_queries_per_sec": nc * n4 / (ms_r * 1e-3),
+                                      "grid_subsample_ms": ms_g, "grid_points_per_sec": nc * n4 / (ms_g * 1e-3)}
+    del pts, table, o
+    # ---- C5: one GPU's share of the 100k x 100k x 256 matching when the reference set is split 8 ways
+    xq, y = c5_features(torch, device)
+    ys = y[: C5_ROWS // 8].contiguous()
+    d = torch.empty((1, C5_ROWS, 3), device=device)
+    i = torch.empty((1, C5_ROWS, 3), dtype=torch.long, device=device)
+    ms = _loop_ms(torch, lambda: ext.knn_feat(xq.unsqueeze(0), ys.unsqueeze(0), d, i, 3), 5, warm=1)
+    tf = 2.0 * C5_ROWS * (C5_ROWS // 8) * C5_DIM / (ms * 1e-3) / 1e12
+    out["c5_matching_one_gpu_shard"] = {"workload": "100000 queries x 12500 references (1/8 of the set) x 256, k=3",
+                                        "ms": ms, "queries_per_sec": C5_ROWS / (ms * 1e-3), "tflops": tf,
+                                        "mfma_frac": tf / MFMA_F32_PEAK_TFLOPS}
+    return out
+
+
+class C5Sharded:
+    """BASELINE config 5 on `world` ranks: queries replicated, reference set split by sharding.batch_bounds, one
+    all-gather of the partial top-k (RCCL) + merge; verified on the device against the single-GPU search."""
+
+    def __init__(self, torch, dist, device, world, rank, k=3):
+        from vision3d_amd import sharding
+
+        self.torch, self.dist, self.sharding, self.k = torch, dist, sharding, k
+        self.world, self.rank = world, rank
+        self.x, self.y = c5_features(torch, device)  # same seed on every rank: replicated inputs
+        self.begin, self.end = sharding.batch_bounds(C5_ROWS, world, rank)
+        self.local = self.y[self.begin:self.end].contiguous()
+
+    def step(self):
+        return self.sharding.knn_reference_sharded(self.x, self.local, self.k, self.begin)
+
+    def verify(self):
+        torch = self.torch
+        d, i = self.step()
+        fd, fi = self.sharding._hip_search(self.x, self.y, self.k, 0)  # the single-GPU result, on this rank
+        ok = bool(torch.equal(i, fi)) and bool(torch.equal(d, fd))
+        flag = torch.tensor([1 if ok else 0], device=self.x.device)
+        if self.world > 1:
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def exchange_ms(self, iters=10):
+        """The collective alone: all-gather of (rows,k) fp32 + int64 partial lists."""
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            return 0.0
+        pd = torch.zeros((C5_ROWS, self.k), device=self.x.device)
+        pi = torch.zeros((C5_ROWS, self.k), dtype=torch.long, device=self.x.device)
+
+        def fn():  # exactly the two calls knn_reference_sharded makes
+            self.sharding._all_gather_rows(pd)
+            self.sharding._all_gather_rows(pi)
+        return _loop_ms(torch, fn, iters)
+
+    def report(self, ms):
+        flops = 2.0 * C5_ROWS * C5_ROWS * C5_DIM
+        return {"workload": f"100000 x 100000 x 256 k={self.k}, reference set split over {self.world} rank(s)",
+                "ms": ms, "queries_per_sec": C5_ROWS / (ms * 1e-3), "tflops_whole_job": flops / (ms * 1e-3) / 1e12,
+                "mfma_frac_per_gpu": flops / self.world / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "allgather_bytes_per_rank": C5_ROWS * self.k * 12,
+                "allgather_bytes_received": self.world * C5_ROWS * self.k * 12}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _trace(msg):
+    if os.environ.get("V3D_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def rank_main(args):
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the operators have no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # reference: utils/distributed.py:14
     device = torch.device("cuda", local_rank)
-    dist = None
+    dist, rccl_world = None, 1
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=device)  # RCCL
+        if args.backend == "nccl":  # RCCL; reference: utils/distributed.py:15
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:  # rehearsal of the rank plumbing on a one-GPU box (gloo stages device tensors through the host)
+            dist.init_process_group(backend="gloo")
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        rccl_world = int(ones.item())
+        assert rccl_world == dist.get_world_size() == world
+        _trace(f"process group up: backend {args.backend}, world {rccl_world}")
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bracket():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    line = {"higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "unit": "queries/s", "metric": "neighbor_queries_per_sec"}
+    if dist is not None:
+        line["collective_backend"] = "rccl (torch nccl)" if args.backend == "nccl" else args.backend
+        line["rccl_world_size"] = rccl_world
+
+    if args.workload == "c5_refset":
+        job = C5Sharded(torch, dist, device, world, rank, k=args.c5_k)
+        _trace("c5 inputs ready")
+        ok = job.verify()
+        _trace(f"c5 verified: {ok}")
+        for _ in range(args.warmup):
+            job.step()
+        bracket()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            job.step()
+        bracket()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        ex_ms = max_over_ranks(job.exchange_ms())
+        if rank == 0:
+            ms = elapsed / args.steps * 1e3
+            rep = job.report(ms)
+            line.update(value=C5_ROWS * args.steps / elapsed, ms_per_step=ms, scaling="strong",
+                        config={"workload": "geotransformer_matching_100k_refset_sharded", "k": args.c5_k,
+                                "sharding": f"reference set x{world}, one all-gather of the partial top-k + merge"},
+                        equals_single_gpu_result=ok, allgather_ms=ex_ms, **{k: rep[k] for k in rep if k != "ms"})
+            tf = rep["tflops_whole_job"] / world
+            line["roofline"] = {"bound": "mfma", "kernel": "pairwise_distance_kernel (fp32 MFMA) inside knn_feat",
+                                "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                                "note": "whole knn_feat call per GPU (distance + top-k + exact refine), not the GEMM alone"}
+            assert ok, "sharded result differs from the single-GPU result"
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     inp = make_inputs(1234 + rank, device)  # every rank owns different clouds (batch sharding)
     # `--streams S` batches are in flight at once, each on its own HIP stream with its own buffers: FPS is a serial
@@ -199,62 +498,76 @@ def main():
             steps.append(Step(inp, device, fused_msg=args.fused_msg))
     torch.cuda.synchronize()
 
-    timers = []
+    timers, dom_timers = [], []
 
-    def run_steps(n, timed=False):
+    def run_steps(n, timed=False, nstr=nstream):
         # Per-operator HIP events go around every launch of every EVENT_EVERY-th timed step (alternating streams): an
-        # event pair is a barrier packet either side of the kernel, and on every step they cost 5-8 % of the step time
-        # (tools/host_overhead.py), which is not the operators' time.
+        # event pair is a barrier packet either side of the kernel, and around all 14 launches of every step they cost
+        # 5-8 % of the step time (tools/host_overhead.py).  The roofline kernel alone carries a pair on every timed step.
         for i in range(n):
-            st = steps[i % nstream]
+            st = steps[i % nstr]
             st.timers = timers if (timed and i % EVENT_EVERY == 0) else None
-            with torch.cuda.stream(streams[i % nstream]):
+            st.dom_timers = dom_timers if timed else None
+            with torch.cuda.stream(streams[i % nstr]):
                 st.run()
 
     run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    bracket()
     t0 = time.perf_counter()
     run_steps(args.steps, timed=True)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    bracket()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    _trace("c2 timed region done")
+
+    # the same step with ONE batch in flight (what a single training step sees): not the headline, printed beside it
+    run_steps(min(args.warmup, 3), nstr=1)
+    bracket()
+    t1 = time.perf_counter()
+    run_steps(args.steps, nstr=1)
+    bracket()
+    elapsed_single = max_over_ranks(time.perf_counter() - t1)
+
+    c5 = None
+    if dist is not None and not args.no_per_config:
+        job = C5Sharded(torch, dist, device, world, rank, k=3)
+        _trace("c5 inputs ready")
+        ok = job.verify()
+        _trace(f"c5 verified: {ok}")
+        bracket()
+        t2 = time.perf_counter()
+        for _ in range(3):
+            job.step()
+        bracket()
+        c5_ms = max_over_ranks(time.perf_counter() - t2) / 3 * 1e3
+        ex_ms = max_over_ranks(job.exchange_ms())
+        c5 = dict(job.report(c5_ms), equals_single_gpu_result=ok, allgather_ms=ex_ms)
+        del job
 
     if rank == 0:
         per_op = {}
-        for name, s, e in timers:
+        for name, s, e in timers + dom_timers:
             per_op.setdefault(name, []).append(s.elapsed_time(e))
         per_op_ms = {k: float(np.mean(v)) for k, v in per_op.items()}
         alg = algorithmic_bytes()
-        dom = "group_gather_feat_k128"
+        dom = DOMINANT
         achieved = alg[dom] / (per_op_ms[dom] * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom)
+                traffic_source = ("profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "command, recorded " + str(tj.get("_recorded", "r01")) + " -- not measured by this run")
             except Exception:
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
-        line = {
-            "metric": "neighbor_queries_per_sec",
+        line.update({
             "value": QUERIES_PER_STEP * args.steps * world / elapsed,
-            "unit": "queries/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True,
+            "ms_per_step_single_stream": elapsed_single / args.steps * 1e3,
+            "value_single_stream": QUERIES_PER_STEP * args.steps * world / elapsed_single,
             "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
             "config": {"workload": "pointnet2_msg_fp_s3dis", "B_per_gpu": B, "N": N, "M": M,
                        "scales": [list(s) for s in SCALES], "C_group": C_FEAT, "C_interp": C_INTERP,
                        "sharding": f"batch x{world} (independent clouds, no data-path collective)",
@@ -262,19 +575,56 @@ def main():
                        "ball_query": "one launch for the 3 MSG scales" if args.fused_msg else "one launch per scale"},
             "fps_points_per_sec": B * N * world / (per_op_ms["fps"] * 1e-3),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": alg[dom], "avg_ms": per_op_ms[dom],
                          "launches_timed": len(per_op[dom])},
             "per_op_ms": per_op_ms,
             "per_op_alg_GBs": {k: alg[k] / (per_op_ms[k] * 1e-3) / 1e9 for k in alg if k in per_op_ms},
-        }
+        })
+        per_config = {}
+        if c5 is not None:
+            per_config["c5_matching_refset_sharded"] = c5
+        if world == 1 and not args.no_per_config:
+            del steps[:]
+            torch.cuda.empty_cache()
+            per_config.update(per_config_single(torch, device))
+        line["per_config"] = per_config
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(1234)
+            line["cpu_baseline"], q = cpu_baseline(1234)
+            line["cpu_baseline_reference"] = cpu_baseline_reference(1234, q)
         elif world == 1:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=("c2", "c5_refset"), default="c2")
+    ap.add_argument("--c5-k", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-config", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="batches in flight (one HIP stream each)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL (default); gloo only to rehearse the rank plumbing where ranks must share a GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (one-GPU rehearsal, with gloo)")
+    ap.add_argument("--fused-msg", action="store_true",
+                    help="one ext.ball_query_multi launch for the three MSG scales instead of the reference's three "
+                         "ball_query calls (same outputs; off by default: the default step is the reference's call pattern)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.share_gpu:
+            import torch  # device_count() does not create a context
+
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    rank_main(args)
 
 
 if __name__ == "__main__":

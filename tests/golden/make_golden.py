@@ -7,6 +7,8 @@ Two kinds of fixture, kept apart by file name:
     - vision3d/ops/pairwise_distance.py         (pure torch, CPU)          -> ref_pairwise_distance.npz
     - vision3d/array_ops/knn.py                 (scipy cKDTree.query)       -> ref_array_knn.npz
     - vision3d/array_ops/ball_query.py          (cKDTree.query_ball_point)  -> ref_array_ball_query.npz
+    - vision3d/array_ops/furthest_point_sample.py  (native_furthest_point_sample, NumPy) -> ref_array_fps.npz
+    - vision3d/ops/knn_interpolate.py, ops/point_cloud_partition.py (pure torch once `.knn` resolves) -> ref_knn_ops.npz
   The CUDA kernels themselves cannot be built or run here (no nvcc, no GPU) and ship no test vectors.
 * ``oracle_*.npz`` -- regression vectors of OUR CPU oracle on tie-stress inputs (lattices, duplicates, N<k,
   empty balls).  They pin the oracle against drift and give the GPU tests a file-based target; they are NOT
@@ -318,6 +320,152 @@ def make_pack_ops_fixtures():
             del sys.modules[name]
 
 
+def _synthetic_vision3d(ext_functions=()):
+    """Registers an empty `vision3d` package whose `utils.misc` is the reference's own file (loaded by path: it imports
+    only torch) and whose `ext` is an empty namespace with the asked-for attribute names, so that modules which call
+    `load_ext("vision3d.ext", [...])` at import time (utils/misc.py:23-27) can be loaded without the unbuilt extension.
+    Returns the sys.modules entries to restore."""
+    import types
+
+    names = ("vision3d", "vision3d.utils", "vision3d.utils.misc", "vision3d.ext")
+    saved = {n: sys.modules.get(n) for n in names}
+    pkg, utils, ext = types.ModuleType("vision3d"), types.ModuleType("vision3d.utils"), types.ModuleType("vision3d.ext")
+    pkg.__path__, utils.__path__ = [], []
+    misc = load_by_path("vision3d.utils.misc", os.path.join(REF, "utils", "misc.py"))
+
+    def _absent(*_a, **_k):
+        raise RuntimeError("vision3d.ext is not built in this container")
+
+    for f in ext_functions:
+        setattr(ext, f, _absent)
+    pkg.utils, pkg.ext, utils.misc = utils, ext, misc
+    sys.modules.update({"vision3d": pkg, "vision3d.utils": utils, "vision3d.utils.misc": misc, "vision3d.ext": ext})
+    return saved
+
+
+def _restore_modules(saved):
+    for n, m in saved.items():
+        if m is None:
+            sys.modules.pop(n, None)
+        else:
+            sys.modules[n] = m
+
+
+def fps_round_gaps(points, indices):
+    """Relative gap between the selected (largest) and the runner-up running min-distance of every FPS round, float64."""
+    p = points.astype(np.float64)
+    dist = np.full(p.shape[0], np.inf)
+    gaps = []
+    for j in range(len(indices) - 1):
+        dist = np.minimum(dist, np.linalg.norm(p - p[indices[j]], axis=1))
+        top = np.sort(dist)[-2:]
+        gaps.append((top[1] - top[0]) / top[1])
+    return np.asarray(gaps)
+
+
+def make_fps_fixtures():
+    """array_ops/furthest_point_sample.py:22-66 `native_furthest_point_sample` (pure NumPy, float64 norms), run by the
+    reference's own file.  The file calls load_ext at import time (:6-8), hence the synthetic parent package.  The clouds are
+    float32 values handed over as float64 (exact), and only clouds whose every round separates winner and runner-up by more
+    than 1e-5 relative are kept (seed bumped otherwise, see `fps_round_gaps`): a float64 reference cannot arbitrate an fp32
+    kernel inside fp32 rounding, and among exact ties the CUDA kernel's order is its launch geometry's (unpinnable)."""
+    saved = _synthetic_vision3d(ext_functions=("sample_nodes_with_fps",))
+    try:
+        afps = load_by_path("ref_array_fps", os.path.join(REF, "array_ops", "furthest_point_sample.py"))
+        out = {}
+        for name, n, m, kind in (("u100", 100, 40, "uniform"), ("u257", 257, 64, "uniform"),
+                                 ("s1024", 1024, 128, "sphere"), ("u1000", 1000, 100, "uniform")):
+            seed = 20261120
+            while True:
+                rng = np.random.default_rng(seed)
+                pts = rng.random((n, 3), dtype=np.float32) if kind == "uniform" else unit_sphere_cloud(rng, 1, n)[0]
+                idx = afps.native_furthest_point_sample(pts.astype(np.float64), min_distance=-1.0, num_samples=m)
+                if fps_round_gaps(pts, idx).min() > 1e-5:
+                    break
+                seed += 1
+            out[f"{name}_pts"], out[f"{name}_idx"], out[f"{name}_seed"] = pts, idx.astype(np.int64), np.int64(seed)
+            assert idx.shape == (m,) and idx[0] == 0
+        np.savez_compressed(os.path.join(HERE, "ref_array_fps.npz"), **out)
+    finally:
+        _restore_modules(saved)
+
+
+def make_knn_ops_fixtures():
+    """ops/knn_interpolate.py and ops/point_cloud_partition.py, run on the CPU.  Both import `.knn` (pykeops, absent) at
+    module level; their own logic is pure torch.  They are loaded as submodules of the synthetic parent package with a
+    stand-in `.knn` submodule whose `keops_knn` / `knn` are built on the REFERENCE's own pairwise_distance + torch.topk --
+    the in-repo pure-torch equivalent the reference itself uses (models/geotransformer/geometric_structure_embedding.py
+    :52,:60).  Inputs are tie-free.  What this pins: everything in the two files except pykeops' arithmetic."""
+    import importlib
+    import types
+
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    saved = _synthetic_vision3d()
+    parent = types.ModuleType("v3dref_ops")
+    parent.__path__ = [os.path.join(REF, "ops")]
+    sys.modules["v3dref_ops"] = parent
+    try:
+        pd = importlib.import_module("v3dref_ops.pairwise_distance")
+        knn_mod = types.ModuleType("v3dref_ops.knn")
+
+        def keops_knn(q_points, s_points, k):
+            d = pd.pairwise_distance(q_points, s_points, squared=False, strict=True)
+            vals, idx = d.topk(k, dim=-1, largest=False)
+            return vals, idx
+
+        def knn(q_points, s_points, k, return_distance=False, **_kw):
+            vals, idx = keops_knn(q_points, s_points, k)
+            return (vals, idx) if return_distance else idx
+
+        knn_mod.keops_knn, knn_mod.knn = keops_knn, knn
+        sys.modules["v3dref_ops.knn"] = knn_mod
+        parent.knn = knn_mod
+        ki = importlib.import_module("v3dref_ops.knn_interpolate")
+        pcp = importlib.import_module("v3dref_ops.point_cloud_partition")
+        rng = np.random.default_rng(20261121)
+        out = {}
+        # ---- knn_interpolate_pack_mode (:43-76) on a neighbour table with absent entries (index == M)
+        n_q, n_s, kk, c = 260, 190, 6, 16
+        q = rng.random((n_q, 3), dtype=np.float32)
+        sp = rng.random((n_s, 3), dtype=np.float32)
+        sf = rng.standard_normal((n_s, c)).astype(np.float32)
+        d = np.linalg.norm(q[:, None].astype(np.float64) - sp[None].astype(np.float64), axis=-1)
+        table = np.argsort(d, axis=1)[:, :kk].astype(np.int64)
+        table[np.take_along_axis(d, table, 1) > 0.2] = n_s  # ordered neighbours, far ones absent (radius-search style)
+        table[7] = n_s
+        out.update(ki_q=q, ki_s=sp, ki_feats=sf, ki_table=table)
+        for k_used in (None, 3):
+            got = ki.knn_interpolate_pack_mode(torch.from_numpy(q), torch.from_numpy(sp), torch.from_numpy(sf),
+                                               torch.from_numpy(table), k=k_used)
+            out[f"ki_pack_k{k_used or 0}"] = got.numpy()
+        # ---- knn_interpolate (:10-40), batch-free form, with and without a distance limit
+        for lim in (None, 0.15):
+            got = ki.knn_interpolate(torch.from_numpy(q), torch.from_numpy(sp), torch.from_numpy(sf), k=3,
+                                     distance_limit=lim)
+            out[f"ki_knn_lim{0 if lim is None else 1}"] = got.numpy()
+        # ---- point_to_node_partition (:40-104)
+        pts = (rng.random((700, 3)).astype(np.float32) * np.float32([3.0, 3.0, 2.5]))
+        nodes = pts[rng.permutation(700)[:23]] + rng.normal(0, 0.05, (23, 3)).astype(np.float32)
+        nodes = np.concatenate([nodes, np.float32([[50.0, 50.0, 50.0]])]).astype(np.float32)  # a node that owns no point
+        out.update(p2n_points=pts, p2n_nodes=nodes)
+        for tag, limit in (("all", None), ("lim", 20)):
+            res = pcp.point_to_node_partition(torch.from_numpy(pts), torch.from_numpy(nodes), point_limit=limit,
+                                              return_count=True)
+            for key, t in zip(("p2n", "sizes", "masks", "knn_idx", "knn_masks"), res):
+                out[f"p2n_{tag}_{key}"] = t.numpy()
+        # ---- ball_query_partition (:107-124) on the stand-in knn
+        res = pcp.ball_query_partition(torch.from_numpy(pts), torch.from_numpy(nodes), 0.45, 24, return_count=True)
+        for key, t in zip(("knn_idx", "knn_masks", "masks", "sizes"), res):
+            out[f"bqp_{key}"] = t.numpy()
+        np.savez_compressed(os.path.join(HERE, "ref_knn_ops.npz"), **out)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        for name in [k_ for k_ in sys.modules if k_.startswith("v3dref_ops")]:
+            del sys.modules[name]
+        _restore_modules(saved)
+
+
 def make_oracle_fixtures():
     rng = np.random.default_rng(7)
     # lattice: 6x6x6 integer grid scaled by 0.25 -> massive distance ties, exactly representable
@@ -351,7 +499,11 @@ def make_oracle_fixtures():
 
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["reference", "select", "matching", "voxelize", "pack", "oracle"]
+    which = sys.argv[1:] or ["reference", "select", "matching", "voxelize", "pack", "oracle", "fps", "knn_ops"]
+    if "fps" in which:
+        make_fps_fixtures()
+    if "knn_ops" in which:
+        make_knn_ops_fixtures()
     if "voxelize" in which:
         make_voxelize_fixtures()
     if "matching" in which:

@@ -150,6 +150,10 @@ def test_pack_gathers_vs_reference_fixture(ext, golden):
     f = feats.clone().requires_grad_(True)
     ops.local_maxpool_pack_mode(f, table).backward(T(g["maxpool_upstream"]))
     assert np.abs(N_(f.grad) - g["maxpool_grad"]).max() <= 1e-5 * scale
+    # a NON-contiguous input that requires grad (a transposed activation): same gradient, in the input's layout
+    ft = feats.t().contiguous().requires_grad_(True)  # (C, N); ft.t() is the (N, C) view handed to the op
+    ops.local_maxpool_pack_mode(ft.t(), table).backward(T(g["maxpool_upstream"]))
+    assert np.abs(N_(ft.grad.t()) - g["maxpool_grad"]).max() <= 1e-5 * scale
 
 
 @pytest.mark.parametrize("n,m,k,c", [(1, 1, 1, 4), (100, 77, 5, 4), (1000, 513, 38, 64), (5000, 3000, 16, 128),
@@ -406,6 +410,30 @@ def test_point_to_node_partition_vs_oracle(ext, oracle_mod, n, m, limit):
     assert np.array_equal(N_(got[3]), knn) and np.array_equal(N_(got[4]), kmask)
     only = ops.point_to_node_partition(T(points), T(nodes), gather_points=False)
     assert len(only) == 1 and np.array_equal(N_(only[0]), p2n)
+
+
+def test_knn_ops_vs_reference_fixture(ext, golden):
+    """ops/knn_interpolate.py and ops/point_cloud_partition.py as the reference's own files computed them on the CPU
+    (tests/golden/ref_knn_ops.npz; their pykeops search replaced by the reference's pairwise_distance + topk)."""
+    from vision3d_amd import ops
+
+    g = golden("ref_knn_ops.npz")
+    q, s, f, table = T(g["ki_q"]), T(g["ki_s"]), T(g["ki_feats"]), T(g["ki_table"])
+    tol = 1e-5 * float(np.abs(g["ki_feats"]).max())
+    for k_used in (None, 3):
+        got = ops.knn_interpolate_pack_mode(q, s, f, table, k=k_used)
+        assert np.abs(N_(got) - g[f"ki_pack_k{k_used or 0}"]).max() <= tol
+    for lim, tag in ((None, 0), (0.15, 1)):
+        got = ops.knn_interpolate(q, s, f, k=3, distance_limit=lim)
+        assert np.abs(N_(got) - g[f"ki_knn_lim{tag}"]).max() <= tol
+    pts, nodes = T(g["p2n_points"]), T(g["p2n_nodes"])
+    for tag, limit in (("all", None), ("lim", 20)):
+        res = ops.point_to_node_partition(pts, nodes, point_limit=limit, return_count=True)
+        for key, got in zip(("p2n", "sizes", "masks", "knn_idx", "knn_masks"), res):
+            assert np.array_equal(N_(got), g[f"p2n_{tag}_{key}"]), (tag, key)
+    res = ops.ball_query_partition(pts, nodes, 0.45, 24, return_count=True)
+    for key, got in zip(("knn_idx", "knn_masks", "masks", "sizes"), res):
+        assert np.array_equal(N_(got), g[f"bqp_{key}"]), key
 
 
 def test_point_to_node_partition_matches_reference_formulation(ext):

@@ -61,6 +61,21 @@ def test_fps_random(ext, oracle_mod, n, m):
     assert np.array_equal(N_(idx), want)
 
 
+@pytest.mark.parametrize("name", ["u100", "u257", "s1024", "u1000"])
+def test_fps_vs_reference_native_fps_fixture(ext, golden, name):
+    """Kernel == the reference's own NumPy FPS (array_ops/furthest_point_sample.py:22-66) on the committed fixture
+    (tests/golden/ref_array_fps.npz: clouds with a clear winner in every round), all clouds of the fixture in one batch
+    position each, and through the NumPy entry point `ext.sample_nodes_with_fps` the reference's array_ops calls."""
+    g = golden("ref_array_fps.npz")
+    pts, want = g[f"{name}_pts"], g[f"{name}_idx"]
+    n, m = pts.shape[0], len(want)
+    dist = torch.full((2, n), 1e10, dtype=torch.float32, device=DEV)
+    idx = torch.zeros((2, m), dtype=torch.long, device=DEV)
+    ext.furthest_point_sample(T(np.stack([pts, pts[::-1]])), dist, idx, m)
+    assert np.array_equal(N_(idx)[0], want)
+    assert np.array_equal(ext.sample_nodes_with_fps(pts, -1.0, m), want)
+
+
 @pytest.mark.parametrize("side,scale", [(4, 0.5), (6, 0.25), (8, 0.125), (11, 0.5), (17, 0.25), (27, 1.0)])
 def test_fps_lattice_ties(ext, oracle_mod, side, scale):
     """Integer lattices: almost every round has many equally-far candidates, so the reference's geometry-dependent
@@ -692,6 +707,28 @@ def test_radius_count_pack_nonfinite_and_refusals(ext, oracle_mod):
         ext.radius_count_pack(T(q), T(s), T(ql), T(sl), out, -1.0)
     with pytest.raises(RuntimeError):
         ext.radius_count_pack(T(q), T(s), T(ql), T(sl), out[:10], 0.2)
+
+
+def test_radius_pack_nonfinite_bounding_box_keeps_to_its_cells(ext, oracle_mod):
+    """A cloud whose supports have no finite bounding box (all NaN; or one support at +inf on every axis) must not disturb
+    the cell lists of its neighbours in the pack, nor leave the workspace: such a cloud falls back to a one-cell grid."""
+    rng = np.random.default_rng(66)
+    q, s, ql, sl = _pack_clouds(rng, (150, 120, 130), (600, 500, 700))
+    nan_cloud = s.copy()
+    nan_cloud[600:1100] = np.nan  # the middle cloud: every support NaN -> bbox stays (+inf, -inf)
+    want = oracle_mod.radius_count_pack(q, nan_cloud, ql, sl, 0.15)
+    out = torch.empty((400,), dtype=torch.long, device=DEV)
+    ext.radius_count_pack(T(q), T(nan_cloud), T(ql), T(sl), out, 0.15)
+    assert np.array_equal(N_(out), want) and np.all(want[150:270] == 0) and want[:150].sum() > 0
+    for radius in (0.15, 1e-4):  # a tiny radius is what used to ask for ~1e9 cells
+        inf_cloud = s.copy()
+        inf_cloud[600 + 7] = np.inf  # one support at (inf, inf, inf) in the middle cloud, next to normal clouds
+        want = oracle_mod.radius_count_pack(q, inf_cloud, ql, sl, radius)
+        ext.radius_count_pack(T(q), T(inf_cloud), T(ql), T(sl), out, radius)
+        assert np.array_equal(N_(out), want)
+        idx = torch.empty((400, 20), dtype=torch.long, device=DEV)
+        ext.radius_search_pack(T(q), T(inf_cloud), T(ql), T(sl), idx, radius, 20)
+        assert np.array_equal(N_(idx), oracle_mod.radius_search_pack(q, inf_cloud, ql, sl, radius, 20))
 
 
 def test_radius_pack_c_abi_null_workspace_and_bad_workspace(ext, oracle_mod):

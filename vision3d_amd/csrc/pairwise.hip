@@ -390,6 +390,17 @@ __device__ __forceinline__ float row16_sum_f32(float v) {  // sum over each row 
   return v;
 }
 
+// Candidates kept per row for k requested neighbours.  The lists are selected on the expansion-form distance
+// (|x|^2 - 2xy + |y|^2 on the MFMA), whose rounding error (~1e-6 of |x|^2 + |y|^2) can swap neighbours whose exact
+// distances are closer than that; the finalize pass re-ranks on the exact difference form.  Keeping a few spare
+// candidates makes the k that come out the k best by EXACT (distance, index) unless more than `spare` columns crowd
+// inside the rounding error of the k-th -- which is also what makes a reference-set-sharded search (partial lists per
+// shard, merged) return exactly the single-device lists.
+__host__ __device__ inline int knn_feat_select_k(int k) {
+  const int spare = k / 4 > 4 ? k / 4 : 4;
+  return k + spare < 64 ? k + spare : 64;
+}
+
 // Final pass: recompute the k selected distances exactly as sqrt(sum_c (x_c - y_c)^2) (what pykeops evaluates,
 // ops/knn.py:25), re-rank by (distance, index) and write fp32 distances + int64 (offset) indices.
 // One wave per query row; for each selected neighbour the 64 lanes split the channels (coalesced row reads) and
@@ -397,7 +408,7 @@ __device__ __forceinline__ float row16_sum_f32(float v) {  // sum over each row 
 __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                 const float* __restrict__ run_d,
                                                                 const int* __restrict__ run_i, int batch, int N, int M,
-                                                                int C, int k, int64_t index_offset, int vec4,
+                                                                int C, int k, int kout, int64_t index_offset, int vec4,
                                                                 float* __restrict__ out_d, int64_t* __restrict__ out_i) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -458,8 +469,10 @@ __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __r
       const int filled = k - __builtin_popcountll(empties);
       rank = filled + __builtin_popcountll(empties & ((1ull << lane) - 1ull));
     }
-    out_d[row * k + rank] = dist;
-    out_i[row * k + rank] = idx >= 0 ? (int64_t)idx + index_offset : (int64_t)-1;
+    if (rank < kout) {  // k - kout spare candidates only guard the selection against the expansion form's rounding
+      out_d[row * kout + rank] = dist;
+      out_i[row * kout + rank] = idx >= 0 ? (int64_t)idx + index_offset : (int64_t)-1;
+    }
   }
 }
 
@@ -552,7 +565,7 @@ int v3d_pairwise_distance_f32(const float* x, const float* y, float* out, int ba
 size_t v3d_knn_feat_workspace_bytes(int batch, int N, int M, int C, int k) {
   (void)C;
   if (batch <= 0 || N <= 0 || M <= 0 || k <= 0) return 0;
-  return v3d::carve_knn_ws(nullptr, batch, N, M, k).bytes;
+  return v3d::carve_knn_ws(nullptr, batch, N, M, v3d::knn_feat_select_k(k)).bytes;
 }
 
 int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* indices, int batch, int N, int M,
@@ -573,6 +586,8 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int64_t rows = (int64_t)batch * N;
   const int Mw = M > 0 ? M : 1;
+  const int kout = k;
+  k = knn_feat_select_k(kout);
   const size_t need = carve_knn_ws(nullptr, batch, N, Mw, k).bytes;
   void* base = workspace;
   bool own = false;
@@ -605,7 +620,7 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
   if (rc == 0) {
     const int vec4 = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     hipLaunchKernelGGL(knn_feat_finalize_kernel, dim3(row_blocks), dim3(256), 0, stream, x, y, ws.run_d, ws.run_i,
-                       batch, N, Mw, C, k, index_offset, vec4, distances, indices);
+                       batch, N, Mw, C, k, kout, index_offset, vec4, distances, indices);
     rc = launch_status(what);
   }
   if (own) {

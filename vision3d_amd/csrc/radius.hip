@@ -165,6 +165,18 @@ __global__ void rs_plan_kernel(const int* __restrict__ bbox, const int64_t* __re
         if (p.dx <= kRsMaxDim && p.dy <= kRsMaxDim && p.dz <= kRsMaxDim && (long long)p.dx * p.dy * p.dz <= cap) break;
         h *= 1.25f;
       }
+      // A cloud whose bounding box is not finite (infinite coordinates; all-NaN supports leave it at +inf / -inf) has no
+      // usable grid: the loop above then ends with dimensions outside [1, kRsMaxDim] or a cell count beyond the
+      // workspace.  Such a cloud gets ONE cell (inv_h = 0: every finite coordinate maps to cell 0, non-finite ones are
+      // clamped into it), i.e. every support is a candidate of every query -- correct, merely brute force.
+      bool finite = true;
+      for (int a = 0; a < 6; ++a) finite = finite && (fabsf(bb[a]) <= 3.0e38f);  // false for inf and NaN
+      if (!finite || p.dx < 1 || p.dy < 1 || p.dz < 1 || p.dx > kRsMaxDim || p.dy > kRsMaxDim || p.dz > kRsMaxDim ||
+          (long long)p.dx * p.dy * p.dz > cap) {
+        p.ox = p.oy = p.oz = 0.f;
+        p.inv_h = 0.f;
+        p.dx = p.dy = p.dz = 1;
+      }
     }
     p.cell_off = cell_off;
     plan[b] = p;

@@ -85,11 +85,13 @@ def _require_cuda(name, *tensors):
 class _LocalMaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, neighbor_indices):
+        # decided before .contiguous(): grad mode is off in here, so the copy of a non-contiguous input has
+        # requires_grad == False although the input takes part in autograd
+        need_grad = ctx.needs_input_grad[0] and neighbor_indices.shape[1] <= 255
         feats = feats.contiguous()
         neighbor_indices = neighbor_indices.contiguous()
         m, k = neighbor_indices.shape
         pooled = feats.new_empty((m, feats.shape[1]))
-        need_grad = feats.requires_grad and k <= 255
         argk = torch.empty((m, feats.shape[1]), dtype=torch.uint8, device=feats.device) if need_grad else None
         ext.local_maxpool_pack(feats, neighbor_indices, pooled, argk)
         ctx.table, ctx.argk, ctx.num_sources = neighbor_indices, argk, feats.shape[0]

@@ -53,6 +53,21 @@ def _hip_merge(parts_d, parts_i):
     return out_d, out_i
 
 
+def _all_gather_rows(part: torch.Tensor, group=None) -> torch.Tensor:
+    """(rows, k) on every rank -> (world * rows, k), rank-major.  RCCL gathers device tensors directly; gloo (CPU tests,
+    one-GPU rehearsals of the rank plumbing) only moves host memory, so device tensors are staged through the host."""
+    world = dist.get_world_size(group)
+    part = part.contiguous()
+    if part.is_cuda and dist.get_backend(group) == "gloo":
+        host = part.cpu()
+        out = host.new_empty((world * host.shape[0],) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(part.device)
+    out = part.new_empty((world * part.shape[0],) + tuple(part.shape[1:]))
+    dist.all_gather_into_tensor(out, part, group=group)
+    return out
+
+
 def knn_reference_sharded(
     queries: torch.Tensor,
     local_refs: torch.Tensor,
@@ -73,11 +88,10 @@ def knn_reference_sharded(
         return part_d, part_i
     world = dist.get_world_size(group)
     rows = part_d.shape[0]
-    all_d = part_d.new_empty((world * rows, k))  # rank-major concatenation == (world, rows, k)
-    all_i = part_i.new_empty((world * rows, k))
-    # the single exchange step of the path: two small all-gathers (fp32 distances, int64 indices)
-    dist.all_gather_into_tensor(all_d, part_d.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_i, part_i.contiguous(), group=group)
+    # the single exchange step of the path: two small all-gathers (fp32 distances, int64 indices); the rank-major
+    # concatenation is the (world, rows, k) layout the merge kernel reads
+    all_d = _all_gather_rows(part_d, group)
+    all_i = _all_gather_rows(part_i, group)
     return merge_fn(all_d.view(world, rows, k), all_i.view(world, rows, k))
 
 
@@ -127,10 +141,8 @@ def mutual_matching_sharded(queries, local_refs, k, ref_offset, num_refs_total, 
         if pad:
             col_d = torch.cat([col_d, col_d.new_full((pad, k), float("inf"))], 0)
             col_i = torch.cat([col_i, col_i.new_full((pad, k), -1)], 0)
-        all_d = col_d.new_empty((world * widest, k))
-        all_i = col_i.new_empty((world * widest, k))
-        dist.all_gather_into_tensor(all_d, col_d.contiguous(), group=group)
-        dist.all_gather_into_tensor(all_i, col_i.contiguous(), group=group)
+        all_d = _all_gather_rows(col_d, group)
+        all_i = _all_gather_rows(col_i, group)
         keep = torch.cat([torch.arange(r * widest, r * widest + (e - b)) for r, (b, e) in enumerate(sizes)])
         keep = keep.to(all_d.device)
         col_d, col_i = all_d[keep], all_i[keep]
