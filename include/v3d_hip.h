@@ -114,6 +114,16 @@ int v3d_three_interp_bwd_f64(const double* target_grads, const int64_t* indices,
                              double* source_grads, int B, int C, int S, int Q, void* workspace,
                              size_t workspace_bytes, int device, void* stream);
 
+/* The same backward for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc) -- NO counterpart in the reference.  It calls no hipMalloc / hipFree / allocating routine: its
+ * scratch is a V3D_NOALLOC_SCRATCH_BYTES array built into the library (one copy per GPU, held until the process ends).
+ * Shapes whose v3d_scatter_workspace_bytes(B, S, Q*3) exceeds that size are refused with V3D_ERR_SIZE_LIMIT (use the
+ * entry point above with a workspace).  All calls on one GPU share the array: calls that overlap on one GPU (two
+ * streams, two threads) race -- serialise them.  Results are bit-identical to v3d_three_interp_bwd_f32. */
+#define V3D_NOALLOC_SCRATCH_BYTES (16u << 20)
+int v3d_three_interp_bwd_noalloc_f32(const float* target_grads, const int64_t* indices, const float* weights,
+                                     float* source_grads, int B, int C, int S, int Q, int device, void* stream);
+
 /* ---- gather / group_gather --------------------------------------------------------------------------
  * replace vision3d::gather_forward/_backward (csrc/cuda/gather/gather.h; gather_cuda.cuh:11-33,37-59) and
  * vision3d::group_gather_forward/_backward (csrc/cuda/group_gather/group_gather.h;

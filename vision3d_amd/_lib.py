@@ -44,6 +44,8 @@ SIGNATURES = {
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _WS + _TAIL),
     "v3d_three_interp_bwd_f64": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _WS + _TAIL),
+    "v3d_three_interp_bwd_noalloc_f32": (
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_gather_fwd": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_group_gather_fwd": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int] + _TAIL),

@@ -21,6 +21,8 @@
 // for bit.  Clouds with more than 4096 sources take a generic path (global CSR, thread per source, L2 gathers).
 #include <algorithm>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace v3d {
@@ -589,9 +591,66 @@ int three_interp_bwd_f64_impl(const double* gout, const int64_t* idx, const doub
                                      wsb, device, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The entry point that allocates nothing (v3d_three_interp_bwd_noalloc_f32): its scratch is a file-scope device
+// array instead of a caller workspace / stream-ordered allocation.  Every GPU holds its own copy of the array at its
+// own address until the process ends; the array's NAME is only a host-side stand-in, so the device address is looked
+// up once per device with hipGetSymbolAddress (that device current) and kept.  Calls on one GPU share the array:
+// overlapping calls on one GPU race (documented in include/v3d_hip.h).
+// ------------------------------------------------------------------------------------------------------
+constexpr size_t kNoAllocScratchBytes = (size_t)V3D_NOALLOC_SCRATCH_BYTES;
+constexpr int kNoAllocMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+static void* g_noalloc_ptr[kNoAllocMaxDevices] = {};
+static std::mutex g_noalloc_mutex;
+
+// the device's address of `scratch`; `device` must be current (the caller holds a DeviceGuard)
+static int noalloc_scratch_ptr(const char* what, int device, void** out) {
+  if (device < 0 || device >= kNoAllocMaxDevices) {
+    set_last_error("%s: device ordinal %d outside [0, %d)", what, device, kNoAllocMaxDevices);
+    return V3D_ERR_INVALID_ARGUMENT;
+  }
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+  if (g_noalloc_ptr[device] == nullptr) {
+    void* ptr = nullptr;
+    V3D_HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), what);
+    if (ptr == nullptr || ((uintptr_t)ptr & 255) != 0) {
+      set_last_error("%s: hipGetSymbolAddress returned an unusable address", what);
+      return V3D_ERR_INVALID_ARGUMENT;
+    }
+    g_noalloc_ptr[device] = ptr;
+  }
+  *out = g_noalloc_ptr[device];
+  return 0;
+}
+
 }  // namespace v3d
 
 extern "C" {
+
+int v3d_three_interp_bwd_noalloc_f32(const float* g, const int64_t* idx, const float* w, float* gs, int B, int C, int S,
+                                     int Q, int device, void* stream) {
+  using namespace v3d;
+  const char* what = "three_interpolate_backward (no-alloc)";
+  V3D_REQUIRE(B >= 0 && C >= 0 && S >= 0 && Q >= 0, what, "negative dimension");
+  if (B == 0 || C == 0 || S == 0) return 0;
+  const size_t need = carve_workspace(nullptr, B, S, (int64_t)Q * 3).bytes;
+  if (need > kNoAllocScratchBytes) {
+    set_last_error("%s: B=%d, S=%d, Q=%d needs %zu bytes of scratch, the built-in array holds %zu; use "
+                   "v3d_three_interp_bwd_f32 with a workspace", what, B, S, Q, need, kNoAllocScratchBytes);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  void* ptr = nullptr;
+  {
+    DeviceGuard guard(device);  // hipGetSymbolAddress answers for the CURRENT device
+    if (guard.rc) return guard.rc;
+    const int rc = noalloc_scratch_ptr(what, device, &ptr);
+    if (rc) return rc;
+  }
+  // from here on the array is `ptr`, never its name: the kernels take it as the workspace argument
+  return scatter_backward<float, 1>(what, g, idx, w, gs, B, C, S, (int64_t)Q * 3, ptr, kNoAllocScratchBytes, device,
+                                    stream);
+}
 
 size_t v3d_scatter_workspace_bytes(int B, int num_sources, int64_t positions_per_batch) {
   if (B <= 0 || num_sources < 0 || positions_per_batch < 0) return 0;
