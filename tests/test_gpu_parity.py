@@ -795,6 +795,57 @@ def test_grid_subsample_pack_native(ext, oracle_mod, case):
     assert np.array_equal(N_(got_p), want_p)  # same order, same summation order: bit-identical
 
 
+def test_c4_full_size_radius_search_count_and_grid_subsample(ext, oracle_mod):
+    """BASELINE config 4 at full size: 16 clouds x 30,000 points in a 3 x 3 x 2.5 m box, radius 0.0625 with
+    limit 38 and a denser radius 0.2 (more hits than the limit), voxel 0.025.  Radius search / count: oracle comparison on
+    a 2,000-query subsample per cloud (the oracle is brute force; a query's row depends on that query and the supports
+    only) plus properties of the whole output; grid subsampling: whole output against the oracle, bit for bit.
+    Reference: ops/radius_search.py:44-107, ops/grid_subsample.py:49-99."""
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(91)
+    nc, n, limit, sub = 16, 30000, 38, 2000
+    pts = (rng.random((nc * n, 3)) * np.float32([3.0, 3.0, 2.5])).astype(np.float32)
+    lengths = np.full((nc,), n, np.int64)
+    tp, tl = T(pts), T(lengths)
+    total = nc * n
+    pick = np.concatenate([c * n + np.sort(rng.choice(n, sub, replace=False)) for c in range(nc)])
+    q_sub, ql_sub = pts[pick], np.full((nc,), sub, np.int64)
+    oracle_mod.set_threads(oracle_mod.max_threads())
+    try:
+        for radius in (0.0625, 0.2):
+            idx = torch.empty((total, limit), dtype=torch.long, device=DEV)
+            ext.radius_search_pack(tp, tp, tl, tl, idx, radius, limit)
+            cnt = torch.empty((total,), dtype=torch.long, device=DEV)
+            ext.radius_count_pack(tp, tp, tl, tl, cnt, radius)
+            got, gcnt = N_(idx), N_(cnt)
+            assert np.array_equal(got[pick], oracle_mod.radius_search_pack(q_sub, pts, ql_sub, lengths, radius, limit))
+            # (the count oracle is single-threaded NumPy: every fourth query of the subsample)
+            assert np.array_equal(gcnt[pick[::4]], oracle_mod.radius_count_pack(q_sub[::4], pts, ql_sub // 4, lengths, radius))
+            # whole output: sentinel padding only at the tail of a row, indices inside the query's own cloud, the query
+            # itself first (distance 0), as many hits as the strict count allows, ascending distance
+            valid = got < total
+            hits = valid.sum(1)
+            assert np.array_equal(valid, np.arange(limit)[None, :] < hits[:, None])
+            cloud = np.repeat(np.arange(nc), n)
+            assert np.all((got // n == cloud[:, None]) | ~valid)
+            assert np.array_equal(got[:, 0], np.arange(total))
+            assert np.all(hits >= np.minimum(gcnt, limit))  # the search keeps d == radius, the count is strict
+            assert np.all(hits[gcnt < limit] <= gcnt[gcnt < limit] + 1)
+            rows = rng.choice(total, 20000, replace=False)
+            nb = np.where(valid[rows], got[rows], rows[:, None])
+            d = np.linalg.norm(pts[nb].astype(np.float64) - pts[rows][:, None, :].astype(np.float64), axis=2)
+            assert np.all(d[valid[rows]] <= radius * (1 + 1e-6))
+            d[~valid[rows]] = np.inf
+            assert np.all(np.diff(d, axis=1)[valid[rows][:, 1:]] >= -1e-7)
+    finally:
+        oracle_mod.set_threads(1)
+    want_p, want_l = oracle_mod.grid_subsample_pack(pts, lengths, 0.025)
+    got_p, got_l = ops.grid_subsample_pack_mode(tp, tl, 0.025)
+    assert np.array_equal(N_(got_l), want_l) and np.array_equal(N_(got_p), want_p)
+    assert 0.3 * total < want_p.shape[0] < total  # the voxel size does subsample
+
+
 def test_feature_knn_full_config_sizes(ext, oracle_mod):
     """C3 (DGCNN EdgeConv: 32 x 1024 x 64, k = 20, self included) against the oracle at full size, and a C5-shaped
     reference-set shard (normalised 256-d features, 100k supports) through size-independent properties: the planted

@@ -204,17 +204,6 @@ __global__ __launch_bounds__(kGatherThreads) void gather_fwd_direct_kernel(
   }
 }
 
-static int gather_mode_override() {  // 0 auto, 1 lds, 2 direct -- benchmarking aid, read once
-  static int mode = -1;
-  if (mode < 0) {
-    const char* s = getenv("V3D_GATHER_MODE");
-    mode = 0;
-    if (s && s[0] == 'l') mode = 1;
-    if (s && s[0] == 'd') mode = 2;
-  }
-  return mode;
-}
-
 template <typename E, int VEC>
 static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, int B, int C, int N, int64_t L,
                              hipStream_t stream) {
@@ -226,8 +215,7 @@ static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, i
   const int buf_elems = (int)(align_up(row_bytes + sizeof(E), 16) / sizeof(E));  // N + zero slot, 16-B multiple
   // positions per workgroup: T threads x R vectors of VEC (512- and 1024-thread tiles were measured: no gain).
   constexpr int R_BIG = 8, R_SMALL = 2;
-  const int mode = gather_mode_override();
-  static const int nt = getenv("V3D_GATHER_NT") ? atoi(getenv("V3D_GATHER_NT")) : 1;
+  const int nt = 1;  // streaming (nontemporal) stores: measured +-1 % against plain stores, kept
   const bool lds_fits = row_bytes <= 32768;
   int T = kGatherThreads, R = R_SMALL, CT = 16;
   int64_t xblocks = 0;
@@ -243,8 +231,6 @@ static int launch_gather_fwd(const void* src_, const int64_t* idx, void* out_, i
   };
   plan(kGatherThreads);
   bool use_lds = vec_store && lds_fits && (int64_t)N * 2 <= (int64_t)T * VEC * R * CT;
-  if (mode == 1) use_lds = vec_store && lds_fits;
-  if (mode == 2) use_lds = false;
   const int64_t yblocks = ceil_div(C, CT);
   if (xblocks * yblocks * B > (int64_t)INT32_MAX) {
     set_last_error("gather_forward: launch of %lld workgroups exceeds the grid limit", (long long)(xblocks * yblocks * B));
@@ -300,8 +286,7 @@ static int gather_fwd_dispatch(const char* what, const void* src, const int64_t*
   DeviceGuard guard(device);
   if (guard.rc) return guard.rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  static const int fused = getenv("V3D_GATHER_FUSED") ? atoi(getenv("V3D_GATHER_FUSED")) : 1;  // 0: tuning aid
-  if (fused && elem == 4) {
+  if (elem == 4) {  // 4-byte rows >= 8 KiB run on group.hip's kernel (returns 1 when the shape is not its case)
     const int rc = group_fused_plain_u32(src, idx, out, B, C, N, L, stream);
     if (rc != 1) return rc;
   }

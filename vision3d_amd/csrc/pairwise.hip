@@ -149,11 +149,7 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-#ifdef V3D_PD_PROBE_NO_MFMA
-          acc[i][j][0] += a[i] * bb[j];  // probe build only: keeps the operands alive without the matrix pipe
-#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
-#endif
     }
   }
   if (tid < 128) x2s[tid] = norm; else y2s[tid - 128] = norm;
@@ -186,11 +182,7 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
         if (vec_out) {
           smem[(wr * 32 + r32) * PD_BN + cl] = d;  // staging row = 32*wr + r32 for this i
         } else {
-#ifdef V3D_PD_PROBE_NO_STORE
-          if (row < N && col < M && d == 12345.f) ob[(int64_t)row * out_ld + col] = d;  // probe build only
-#else
           if (row < N && col < M) ob[(int64_t)row * out_ld + col] = d;
-#endif
         }
       }
     }
@@ -204,9 +196,6 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
         const int col = col0 + c4;
         if (row < N && col < M) {  // M % 4 == 0 here, so col < M covers the whole vector
           const float4 v = *reinterpret_cast<const float4*>(&smem[srow * PD_BN + c4]);
-#ifdef V3D_PD_PROBE_NO_STORE
-          if (v.x == 12345.f)
-#endif
           *reinterpret_cast<float4*>(&ob[(int64_t)row * out_ld + col]) = v;
         }
       }

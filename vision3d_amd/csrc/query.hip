@@ -612,10 +612,8 @@ static int three_nn(const T* q, const T* s, T* od, int64_t* oi, int B, int Q, in
       const size_t lds = (size_t)S * sizeof(float4);
       // a few supports per cell: the 27 cells around a query then hold its three nearest almost always (one ring);
       // measured at S = 1024: G = 4 79 us, 5 51-53, 6 51-57, 7 55-62, 8 63 (brute force: 92)
-      static const int tune = getenv("V3D_TNN_G") ? atoi(getenv("V3D_TNN_G")) : 0;  // tuning aid
-      const int g = tune ? tune : (S >= 1600 ? 7 : (S >= 900 ? 6 : (S >= 384 ? 5 : 4)));  // ~5-8 supports per cell
-      if (g == 8) hipLaunchKernelGGL((three_nn_grid_kernel<8>), grid, block, lds, stream, q, s, od, oi, Q, S);
-      else if (g == 7) hipLaunchKernelGGL((three_nn_grid_kernel<7>), grid, block, lds, stream, q, s, od, oi, Q, S);
+      const int g = S >= 1600 ? 7 : (S >= 900 ? 6 : (S >= 384 ? 5 : 4));  // ~5-8 supports per cell
+      if (g == 7) hipLaunchKernelGGL((three_nn_grid_kernel<7>), grid, block, lds, stream, q, s, od, oi, Q, S);
       else if (g == 6) hipLaunchKernelGGL((three_nn_grid_kernel<6>), grid, block, lds, stream, q, s, od, oi, Q, S);
       else if (g == 5) hipLaunchKernelGGL((three_nn_grid_kernel<5>), grid, block, lds, stream, q, s, od, oi, Q, S);
       else hipLaunchKernelGGL((three_nn_grid_kernel<4>), grid, block, lds, stream, q, s, od, oi, Q, S);
@@ -1086,7 +1084,7 @@ static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, 
   dim3 grid((unsigned)ceil_div(M, kWavesPerBlock * QPW), (unsigned)B), block(kQueryThreads);
   if constexpr (std::is_same<T, float>::value) {
     // batched survivors + bitonic merge: 14-25 % faster than the list from k ~ 24 up, slower below k ~ 12
-    if (k >= 24 && k + 1 <= 64 && getenv("V3D_KNN_LIST") == nullptr) {
+    if (k >= 24 && k + 1 <= 64) {
       hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
       return launch_status(what);
     }

@@ -28,13 +28,14 @@
 namespace v3d {
 
 constexpr int kChunkCols = 2048;      // columns of grad_out per chunk (MODE 1: three entries per column)
+constexpr int kInterpChunkCols = 1024;  // MODE 1: a target row is short (Q ~ 4096), smaller chunks = a deeper load pipeline
 constexpr int kMaxLdsSources = 4096;  // acc[N][CT] must fit LDS beside the tile
 constexpr int kScatterThreads = 1024;
 constexpr unsigned kNoSegment = 0xFFFFFFFFu;
 
 template <int MODE>
 struct ChunkGeom {
-  static constexpr int P = kChunkCols;
+  static constexpr int P = MODE == 1 ? kInterpChunkCols : kChunkCols;
   static constexpr int EMAX = MODE == 1 ? 3 * P : P;  // entries (target positions) a chunk can hold
 };
 
@@ -181,7 +182,8 @@ struct ChunkRegs {
   static constexpr int kEntV = (kEntVecs + kScatterThreads - 1) / kScatterThreads;
   static constexpr int kWVecs = ChunkGeom<MODE>::EMAX * (int)sizeof(T) / 16;
   static constexpr int kWV = MODE == 1 ? (kWVecs + kScatterThreads - 1) / kScatterThreads : 1;
-  static constexpr int kSeg = MODE == 1 ? 4 : 2;  // segment slots per thread: min(N, EMAX) / 1024
+  static constexpr int kSegMax = ChunkGeom<MODE>::EMAX < kMaxLdsSources ? ChunkGeom<MODE>::EMAX : kMaxLdsSources;
+  static constexpr int kSeg = (kSegMax + kScatterThreads - 1) / kScatterThreads;  // segment slots per thread
   static_assert(kRows >= 1 && CT * kGroups % kScatterThreads == 0, "tile must split evenly over the workgroup");
   uint4 t[kRows];
   uint4 e[kEntV];
@@ -513,7 +515,7 @@ int scatter_backward(const char* what, const T* gout, const int64_t* idx, const 
   }
   const int64_t Lrow = MODE == 1 ? L / 3 : L;
   const bool chunked = N <= kMaxLdsSources;
-  const int nchunks = (int)std::max<int64_t>(1, ceil_div(Lrow, kChunkCols));
+  const int nchunks = (int)std::max<int64_t>(1, ceil_div(Lrow, ChunkGeom<MODE>::P));
   if ((int64_t)ceil_div(C, 2) * B > (int64_t)INT32_MAX) {
     set_last_error("%s: launch exceeds the grid limit", what);
     return V3D_ERR_SIZE_LIMIT;
