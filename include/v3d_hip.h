@@ -29,11 +29,14 @@ extern "C" {
 
 #define V3D_OK 0
 #define V3D_ERR_INVALID_ARGUMENT (-1) /* null pointer, negative size, unsupported element width ... */
-#define V3D_ERR_K_TOO_LARGE (-2)      /* knn_points: k > 100 (reference: best_dist[100], knn_points_cuda.cuh:68) */
+#define V3D_ERR_K_TOO_LARGE (-2)      /* knn_points: k > 100 (reference: best_dist[100], knn_points_cuda.cuh:68); the
+                                         other searches: k beyond the V3D_*_MAX_* stated at their declarations */
 #define V3D_ERR_WORKSPACE (-3)        /* caller workspace smaller than v3d_scatter_workspace_bytes() */
 #define V3D_ERR_SIZE_LIMIT (-4)       /* a dimension exceeds what the 32-bit index VALUES can express */
 
 #define V3D_KNN_MAX_K 100
+#define V3D_KNN_FEAT_MAX_K 2048       /* v3d_knn_feat_f32 */
+#define V3D_RADIUS_MAX_LIMIT 512      /* v3d_radius_search_pack_f32 */
 
 /* Library identification / diagnostics (no reference counterpart). */
 int v3d_version(void);                       /* 10000*major + 100*minor + patch */
@@ -157,8 +160,9 @@ int v3d_group_gather_bwd_f64(const double* target_grads, const int64_t* indices,
  * exact difference form of :28-37 on the VALU: sum_c (x_c-y_c)^2, or its sqrt with bit1; no clamp, no eps).
  * v3d_knn_feat_f32 is the fused form behind ops/knn.py:10-27 (pykeops Kmin_argKmin of the Euclidean norm):
  * k smallest by (distance, index), distances (batch,N,k) NOT squared, indices (batch,N,k) i64, offset by
- * `index_offset` (reference-set sharding).  k <= 64.  `workspace` as above, size from
- * v3d_knn_feat_workspace_bytes(); NULL = stream-ordered allocation. */
+ * `index_offset` (reference-set sharding).  k <= V3D_KNN_FEAT_MAX_K (pykeops has no limit; k <= 64 runs
+ * a wave per query row, larger k a workgroup per row -- slower, same results); slots beyond M come out as (inf, -1).
+ * `workspace` as above, size from v3d_knn_feat_workspace_bytes(); NULL = stream-ordered allocation. */
 #define V3D_PD_NORMALIZED 1
 #define V3D_PD_SQRT 2
 #define V3D_PD_STRICT 4
@@ -178,7 +182,8 @@ int v3d_topk_merge_f32(const float* parts_dist, const int64_t* parts_idx, float*
  *
  * Radius search, replaces vision3d/ops/radius_search.py:44-71 (pack -> padded batch -> pykeops kNN -> mask -> pack):
  * neighbor_indices (total_q, neighbor_limit) = the supports of the query's own cloud with NOT(sqrt(d2) > radius),
- * ascending by (d2, index), first `neighbor_limit` (<= 128), padded with total_s.  The lengths must sum to the totals.
+ * ascending by (d2, index), first `neighbor_limit` (<= V3D_RADIUS_MAX_LIMIT), padded with total_s.  The lengths must sum
+ * to the totals.
  * No host synchronisation.  Scratch: v3d_radius_search_workspace_bytes(B, total_s) bytes or NULL (stream-ordered
  * allocation). */
 size_t v3d_radius_search_workspace_bytes(int B, int64_t total_s);
@@ -186,6 +191,16 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
                                const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q,
                                int64_t total_s, float radius, int neighbor_limit, void* workspace,
                                size_t workspace_bytes, int device, void* stream);
+/* Pack-mode kNN, replaces vision3d/ops/knn.py:110-145 (pack -> batch padded with points at 1e10 -> pykeops kNN -> pack):
+ * for every query the k nearest supports of ITS OWN cloud: distances (total_q,k) = sqrt of the squared distance,
+ * ascending; indices (total_q,k) i64 = positions inside the cloud (what the reference's padded batch yields), order among
+ * equal distances as v3d_knn_points_f32.  k <= V3D_KNN_MAX_K; a cloud with fewer than k supports (the reference asserts
+ * against it, :137) leaves (1e5, 0) in the unfilled slots like v3d_knn_points_f32.  No host synchronisation.  Scratch:
+ * v3d_knn_pack_workspace_bytes(B) bytes or NULL (stream-ordered allocation). */
+size_t v3d_knn_pack_workspace_bytes(int B);
+int v3d_knn_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
+                     float* distances, int64_t* indices, int B, int64_t total_q, int64_t total_s, int k,
+                     void* workspace, size_t workspace_bytes, int device, void* stream);
 /* Radius count, replaces vision3d/ops/radius_search.py:74-107 (pack -> padded batch -> pykeops sum of
  * relu(radius - d).sign() -> pack): counts (total_q,) = the number of supports of the query's own cloud with
  * radius - sqrt(d2) > 0 (strict).  Same cell list, workspace and limits as the search above. */

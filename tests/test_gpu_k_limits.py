@@ -1,0 +1,277 @@
+"""Searches beyond the lane-list sizes, and pack-mode kNN without padding:
+  * v3d_knn_feat_f32 with k > 64 (workgroup-per-row selection; pykeops' Kmin_argKmin, ops/knn.py:26, has no limit);
+  * v3d_radius_search_pack_f32 with neighbor_limit > 128 (ops/radius_search.py:44-71 passes any limit to pykeops);
+  * v3d_knn_pack_f32 behind ops.knn_pack_mode (ops/knn.py:110-145) against the knn_points oracle, cloud by cloud.
+Bars as in test_gpu_parity.py: indices bit-exact for the 3-D searches; the feature search to fp32 distance resolution."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import lattice_cloud
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+knn_mod = importlib.import_module("vision3d_amd.ops.knn")  # `ops.knn` is the function
+
+
+@pytest.fixture(scope="module")
+def ext():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from vision3d_amd import _lib, ext as ext_mod
+
+    assert os.path.exists(_lib.LIB_PATH), "libv3d_hip.so must be built in-tree before the GPU run"
+    _lib.lib()
+    return ext_mod
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def _check_knn_feat(ext, oracle_mod, x, y, k):
+    b, n, _ = x.shape
+    m = y.shape[1]
+    oracle_mod.set_threads(oracle_mod.max_threads())
+    try:
+        wd, wi = oracle_mod.knn_feat(x, y, k)
+    finally:
+        oracle_mod.set_threads(1)
+    d = torch.empty((b, n, k), device=DEV)
+    idx = torch.empty((b, n, k), dtype=torch.long, device=DEV)
+    ext.knn_feat(T(x), T(y), d, idx, k)
+    gd, gi = N_(d), N_(idx)
+    kk = min(k, m)
+    assert np.all(gi[..., kk:] == -1) and np.all(np.isinf(gd[..., kk:]))
+    scale = np.sqrt((x ** 2).sum(-1))[..., None] + np.sqrt((y ** 2).sum(-1)).max()
+    tol = 1e-5 * np.broadcast_to(scale, gd[..., :kk].shape) + 1e-6
+    assert np.all(np.abs(gd[..., :kk] - wd[..., :kk]) <= tol)
+    assert np.all(np.diff(gd[..., :kk], axis=-1) >= 0)
+    assert np.all((gi[..., :kk] >= 0) & (gi[..., :kk] < m))
+    srt = np.sort(gi[..., :kk], axis=-1)
+    assert np.all(np.diff(srt, axis=-1) > 0)  # no column twice
+    mismatch = gi[..., :kk] != wi[..., :kk]
+    assert mismatch.mean() < 2e-3  # any index mismatch is a near-tie: same distance at that rank (checked above)
+    return gd, gi, wd, wi
+
+
+@pytest.mark.parametrize("shape", [(1, 50, 300, 16, 65), (2, 40, 700, 32, 128), (1, 20, 5000, 8, 500), (1, 10, 90, 8, 128),
+                                   (1, 4, 3000, 4, 2048), (1, 33, 200, 3, 150)])
+def test_knn_feat_k_above_64(ext, oracle_mod, shape):
+    b, n, m, c, k = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((b, n, c)).astype(np.float32)
+    y = rng.standard_normal((b, m, c)).astype(np.float32)
+    _check_knn_feat(ext, oracle_mod, x, y, k)
+
+
+def test_knn_feat_large_k_exact_ties_come_in_index_order(ext, oracle_mod):
+    """Every reference row appears three times: equal distances (identical arithmetic) must come lowest index first."""
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((1, 120, 16)).astype(np.float32)
+    y = np.concatenate([base, base, base], axis=1)
+    x = rng.standard_normal((1, 30, 16)).astype(np.float32)
+    gd, gi, wd, wi = _check_knn_feat(ext, oracle_mod, x, y, 100)
+    same = gd[..., 1:] == gd[..., :-1]
+    assert same.mean() > 0.5
+    assert np.all(gi[..., 1:][same] > gi[..., :-1][same])
+    assert np.array_equal(gi, wi)
+
+
+def test_knn_feat_large_k_over_several_column_chunks(ext, oracle_mod):
+    """4096 x 16384 distances exceed the 128 MiB chunk: the running list is carried from chunk to chunk."""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((1, 4096, 8)).astype(np.float32)
+    y = rng.standard_normal((1, 16384, 8)).astype(np.float32)
+    k = 70
+    d = torch.empty((1, 4096, k), device=DEV)
+    idx = torch.empty((1, 4096, k), dtype=torch.long, device=DEV)
+    ext.knn_feat(T(x), T(y), d, idx, k)
+    gd, gi = N_(d), N_(idx)
+    rows = np.arange(0, 4096, 16)  # the oracle on a sample of the rows
+    oracle_mod.set_threads(oracle_mod.max_threads())
+    try:
+        wd, wi = oracle_mod.knn_feat(x[:, rows], y, k)
+    finally:
+        oracle_mod.set_threads(1)
+    assert np.all(np.abs(gd[:, rows] - wd) <= 1e-4)
+    assert (gi[:, rows] != wi).mean() < 2e-3
+    assert np.all(np.diff(gd, axis=-1) >= 0) and np.all((gi >= 0) & (gi < 16384))
+    # both chunks contribute
+    assert (gi < 8192).any() and (gi >= 8192).any()
+
+
+def test_knn_feat_sharded_equals_single_shot_large_k(ext):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((1, 100, 24)).astype(np.float32)
+    y = rng.standard_normal((1, 1200, 24)).astype(np.float32)
+    k, G = 100, 3
+    full_d = torch.empty((1, 100, k), device=DEV)
+    full_i = torch.empty((1, 100, k), dtype=torch.long, device=DEV)
+    ext.knn_feat(T(x), T(y), full_d, full_i, k)
+    pd = torch.empty((G, 100, k), device=DEV)
+    pi = torch.empty((G, 100, k), dtype=torch.long, device=DEV)
+    for g in range(G):
+        ys = np.ascontiguousarray(y[:, g * 400:(g + 1) * 400])
+        ext.knn_feat(T(x), T(ys), pd[g:g + 1], pi[g:g + 1], k, index_offset=g * 400)
+    od = torch.empty((100, k), device=DEV)
+    oi = torch.empty((100, k), dtype=torch.long, device=DEV)
+    ext.topk_merge(pd, pi, od, oi)
+    assert torch.equal(oi, full_i[0]) and torch.equal(od, full_d[0])
+
+
+def test_knn_limits_are_errors_not_crashes(ext):
+    from vision3d_amd import ops
+
+    x = torch.zeros((1, 4, 8), device=DEV)
+    with pytest.raises(RuntimeError, match="V3D_ERR_K_TOO_LARGE"):
+        ext.knn_feat(x, x, torch.zeros((1, 4, 2049), device=DEV), torch.zeros((1, 4, 2049), dtype=torch.long, device=DEV),
+                     2049)
+    with pytest.raises(RuntimeError, match="exceeds 2048"):
+        knn_mod.keops_knn(x, x, 2049)
+    q = torch.zeros((4, 3), device=DEV)
+    ln = torch.tensor([4], device=DEV)
+    with pytest.raises(RuntimeError, match="V3D_ERR_K_TOO_LARGE"):
+        ext.radius_search_pack(q, q, ln, ln, torch.zeros((4, 513), dtype=torch.long, device=DEV), 0.1, 513)
+    with pytest.raises(RuntimeError, match="V3D_ERR_K_TOO_LARGE"):
+        ext.knn_pack(q, q, ln, ln, torch.zeros((4, 101), device=DEV), torch.zeros((4, 101), dtype=torch.long, device=DEV),
+                     101)
+
+
+def test_knn_wrapper_3d_large_k_and_dilation(ext, oracle_mod):
+    """3-D points with k > 100 leave the knn_points kernels for the feature route; dilated lists need k*dilation."""
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(8)
+    pts = rng.random((2, 600, 3), dtype=np.float32)
+    d, i = ops.knn(T(pts), T(pts), 130, return_distance=True)
+    wd, wi = oracle_mod.knn_feat(pts, pts, 130)
+    assert (N_(i) != wi).mean() < 2e-3 and np.allclose(N_(d), wd, atol=1e-5)
+    i2 = ops.knn(T(pts), T(pts), 40, dilation=4, remove_nearest=True)  # searches 1 + 39*4 + 1 = 158 neighbours
+    wd2, wi2 = oracle_mod.knn_feat(pts, pts, 158)
+    assert (N_(i2) != wi2[..., 1::4]).mean() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------------
+# radius search with neighbor_limit > 128
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    dict(q=(200, 0, 100), s=(1500, 10, 900), r=0.25, k=200),       # R = 4 list; hits below and above the limit
+    dict(q=(150,), s=(3000,), r=0.3, k=512),                       # R = 8 list
+    dict(q=(300,), s=(512,), r=0.4, k=300, lattice=8),             # lattice: (d2, index) ties across the list
+    dict(q=(64, 64), s=(100, 2000), r=5.0, k=129),                 # radius covers everything: the first 129 of each cloud
+])
+def test_radius_search_pack_large_limits(ext, oracle_mod, case):
+    rng = np.random.default_rng(71)
+
+    def cloud(n):
+        if case.get("lattice"):
+            return (rng.integers(0, case["lattice"], (n, 3)) / case["lattice"]).astype(np.float32)
+        return rng.random((n, 3)).astype(np.float32)
+
+    q = np.concatenate([cloud(n) for n in case["q"]] + [np.zeros((0, 3), np.float32)])
+    s = np.concatenate([cloud(n) for n in case["s"]] + [np.zeros((0, 3), np.float32)])
+    ql, sl = np.asarray(case["q"], np.int64), np.asarray(case["s"], np.int64)
+    want = oracle_mod.radius_search_pack(q, s, ql, sl, case["r"], case["k"])
+    out = torch.full((q.shape[0], case["k"]), -7, dtype=torch.long, device=DEV)
+    ext.radius_search_pack(T(q), T(s), T(ql), T(sl), out, case["r"], case["k"])
+    assert np.array_equal(N_(out), want)
+    from vision3d_amd import ops
+
+    got = ops.radius_search_pack_mode(T(q), T(s), T(ql), T(sl), case["r"], case["k"])
+    assert np.array_equal(N_(got), want)
+
+
+def test_radius_neighbors_numpy_entry_widens_its_table(ext, oracle_mod):
+    rng = np.random.default_rng(72)
+    pts = rng.random((1500, 3)).astype(np.float32)
+    lengths = np.asarray([1000, 500], np.int64)
+    table = ext.radius_neighbors(pts, pts, lengths, lengths, 0.3)  # up to ~150 neighbours per query
+    assert 128 < table.shape[1] < 512
+    want = oracle_mod.radius_search_pack(pts, pts, lengths, lengths, 0.3, table.shape[1])
+    assert np.array_equal(table, want)
+
+
+# ------------------------------------------------------------------------------------------------------
+# pack-mode kNN on the packed arrays
+# ------------------------------------------------------------------------------------------------------
+def _knn_pack_oracle(oracle_mod, q, s, ql, sl, k):
+    d = np.zeros((q.shape[0], k), np.float32)
+    i = np.zeros((q.shape[0], k), np.int64)
+    qo = so = 0
+    for a, b in zip(ql, sl):
+        if a:
+            wd, wi = oracle_mod.knn_points(q[None, qo:qo + a], s[None, so:so + b], k)
+            d[qo:qo + a], i[qo:qo + a] = wd[0], wi[0]
+        qo += a
+        so += b
+    return d, i
+
+
+@pytest.mark.parametrize("case", [
+    dict(q=(150, 90, 200), s=(150, 90, 200)),
+    dict(q=(17, 0, 1, 400, 16), s=(300, 50, 120, 2500, 101)),   # empty query cloud, single query, partly filled workgroups
+    dict(q=(1000,), s=(1200,)),
+    dict(q=(216, 100), s=(216, 512), lattice=True),               # equal distances: the heap replay decides
+])
+@pytest.mark.parametrize("k", [1, 5, 16, 30, 63, 64, 100])
+def test_knn_pack_native_vs_per_cloud_oracle(ext, oracle_mod, case, k):
+    rng = np.random.default_rng(73)
+    if case.get("lattice"):
+        sc = [lattice_cloud(6, 0.25)[0], lattice_cloud(8, 0.125, shuffle_seed=1)[0]]
+        qc = [sc[0].copy(), sc[1][:100].copy()]
+    else:
+        sc = [rng.random((n, 3), dtype=np.float32) for n in case["s"]]
+        qc = [rng.random((n, 3), dtype=np.float32) for n in case["q"]]
+    q, s = np.concatenate(qc), np.concatenate(sc)
+    ql, sl = np.asarray(case["q"], np.int64), np.asarray(case["s"], np.int64)
+    wd, wi = _knn_pack_oracle(oracle_mod, q, s, ql, sl, k)
+    d = torch.full((q.shape[0], k), -1.0, device=DEV)
+    idx = torch.full((q.shape[0], k), -7, dtype=torch.long, device=DEV)
+    ext.knn_pack(T(q), T(s), T(ql), T(sl), d, idx, k)
+    assert np.array_equal(N_(idx), wi)
+    assert np.array_equal(N_(d), wd)
+
+
+def test_knn_pack_mode_op_matches_padded_route_and_keeps_the_assertion(ext, oracle_mod):
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(74)
+    ql, sl = [130, 70, 260], [400, 90, 333]
+    q = rng.random((sum(ql), 3), dtype=np.float32)
+    s = rng.random((sum(sl), 3), dtype=np.float32)
+    tq, ts = T(q), T(s)
+    tql, tsl = torch.tensor(ql, device=DEV), torch.tensor(sl, device=DEV)
+    for k in (1, 8, 32):
+        d, i = ops.knn_pack_mode(tq, ts, tql, tsl, k, return_distance=True)
+        pd, pi = knn_mod.padded_knn_pack_mode(tq, ts, tql, tsl, k, return_distance=True)
+        assert torch.equal(i, pi) and torch.equal(d, pd)
+        assert torch.equal(ops.knn_pack_mode(tq, ts, tql, tsl, k), i)
+    with pytest.raises(AssertionError, match="less than 91"):
+        ops.knn_pack_mode(tq, ts, tql, tsl, 91)
+    # k above the knn_points limit: padded route through the feature kernels
+    sl2 = torch.tensor([400, 190, 233], device=DEV)  # the same 823 supports cut differently: every cloud >= 120
+    i = ops.knn_pack_mode(tq, ts, tql, sl2, 120)
+    pi = knn_mod.padded_knn_pack_mode(tq, ts, tql, sl2, 120)
+    assert i.shape == (sum(ql), 120) and torch.equal(i, pi)
+    for c, (qo, n) in enumerate(zip((0, 130, 200), (400, 190, 233))):
+        rows = i[qo:qo + ql[c]]
+        assert int(rows.min()) >= 0 and int(rows.max()) < n
+
+
+def test_knn_pack_lengths_that_overrun_the_arrays_are_cut(ext):
+    """Lengths are device data nobody validated: a sum beyond the arrays must not read or write outside them."""
+    q = torch.rand((100, 3), device=DEV)
+    s = torch.rand((80, 3), device=DEV)
+    d = torch.full((100, 4), -1.0, device=DEV)
+    i = torch.full((100, 4), -7, dtype=torch.long, device=DEV)
+    ext.knn_pack(q, s, torch.tensor([60, 500], device=DEV), torch.tensor([50, 10 ** 9], device=DEV), d, i, 4)
+    torch.cuda.synchronize()
+    assert int(i[:60].max()) < 50 and int(i[60:].max()) < 30 and int(i.min()) >= 0

@@ -67,6 +67,9 @@ SIGNATURES = {
     "v3d_radius_search_workspace_bytes": (_c_size, [_c_int, _c_i64]),
     "v3d_radius_search_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32, _c_int] + _WS + _TAIL),
+    "v3d_knn_pack_workspace_bytes": (_c_size, [_c_int]),
+    "v3d_knn_pack_f32": (
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_int] + _WS + _TAIL),
     "v3d_radius_count_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32] + _WS + _TAIL),
     "v3d_mutual_topk_select_f32": (

@@ -387,6 +387,7 @@ __device__ __forceinline__ float row16_sum_f32(float v) {  // sum over each row 
 // shard, merged) return exactly the single-device lists.
 __host__ __device__ inline int knn_feat_select_k(int k) {
   const int spare = k / 4 > 4 ? k / 4 : 4;
+  if (k > 64) return k + spare;  // the workgroup-per-row kernels: no lane-list limit
   return k + spare < 64 ? k + spare : 64;
 }
 
@@ -461,6 +462,170 @@ __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __r
     if (rank < kout) {  // k - kout spare candidates only guard the selection against the expansion form's rounding
       out_d[row * kout + rank] = dist;
       out_i[row * kout + rank] = idx >= 0 ? (int64_t)idx + index_offset : (int64_t)-1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k > 64 (pykeops' Kmin_argKmin has no limit, ops/knn.py:26): one WORKGROUP per row, selection by value instead of a
+// lane list.  The pool of a pass is the row's running list (k slots from earlier chunks) followed by this chunk's
+// columns; an element's key is (distance bits, index), both unsigned -- distances are >= +0, so the bit pattern orders
+// like the value; unfilled slots carry (0xffffffff, 0x80000000 + slot) and sort behind everything.  Two bit-wise binary
+// searches (each step: count the keys below a trial, block-wide) find the k-th smallest distance and, among the
+// columns that tie with it, the index that completes the k; the k elements at or below that pair are gathered in LDS
+// and ranked against each other.  The pool is re-read from memory (L2 / Infinity Cache) on every step: this path
+// trades speed for having no limit but LDS (kKnnLargeMaxK entries).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kKnnLargeMaxK = 2560;  // candidates per row: 2048 requested + a quarter spare
+static_assert(V3D_KNN_FEAT_MAX_K + V3D_KNN_FEAT_MAX_K / 4 <= kKnnLargeMaxK, "the selection's LDS list holds k + k/4 entries");
+constexpr unsigned kEmptyKey = 0xffffffffu, kEmptyIdx = 0x80000000u;
+
+__device__ __forceinline__ int block_sum_256(int v, int* red) {  // every thread of a 256-thread workgroup calls it
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void topk_rows_large_kernel(const float* __restrict__ D, int ncols, int64_t ld,
+                                                              int col_base, int k, int first_chunk,
+                                                              float* __restrict__ run_d, int* __restrict__ run_i) {
+  extern __shared__ uint2 sel[];  // k gathered (distance bits, index)
+  __shared__ int red[4];
+  __shared__ int fill;
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const float* drow = D + row * ld;
+  float* rd = run_d + row * k;
+  int* ri = run_i + row * k;
+  const int kprev = first_chunk ? 0 : k;
+  const int pool = kprev + ncols;
+  const int need = pool < k ? pool : k;
+  auto element = [&](int e, unsigned& key, unsigned& idx) {
+    if (e < kprev) {
+      const int i = ri[e];
+      const float d = rd[e];
+      key = i < 0 ? kEmptyKey : (d == 0.f ? 0u : __float_as_uint(d));
+      idx = i < 0 ? kEmptyIdx + (unsigned)e : (unsigned)i;
+    } else {
+      const float d = drow[e - kprev];
+      key = d == 0.f ? 0u : __float_as_uint(d);
+      idx = (unsigned)(col_base + (e - kprev));
+    }
+  };
+  unsigned T = 0, I = 0xffffffffu;
+  if (need > 0 && need < pool) {
+    for (int bit = 31; bit >= 0; --bit) {  // T = need-th smallest distance pattern
+      const unsigned trial = T | (1u << bit);
+      int c = 0;
+      for (int e = tid; e < pool; e += 256) {
+        unsigned key, idx;
+        element(e, key, idx);
+        c += key < trial ? 1 : 0;
+      }
+      if (block_sum_256(c, red) <= need - 1) T = trial;
+    }
+    int below = 0, equal = 0;
+    for (int e = tid; e < pool; e += 256) {
+      unsigned key, idx;
+      element(e, key, idx);
+      below += key < T ? 1 : 0;
+      equal += key == T ? 1 : 0;
+    }
+    below = block_sum_256(below, red);
+    equal = block_sum_256(equal, red);
+    const int ties = need - below;  // >= 1 columns at distance T belong to the k; lowest indices first
+    if (ties < equal) {
+      I = 0;
+      for (int bit = 31; bit >= 0; --bit) {  // I = ties-th smallest index among the columns at distance T
+        const unsigned trial = I | (1u << bit);
+        int c = 0;
+        for (int e = tid; e < pool; e += 256) {
+          unsigned key, idx;
+          element(e, key, idx);
+          c += (key == T && idx < trial) ? 1 : 0;
+        }
+        if (block_sum_256(c, red) <= ties - 1) I = trial;
+      }
+    }
+  } else {
+    T = 0xffffffffu;  // the whole pool
+  }
+  if (tid == 0) fill = 0;
+  __syncthreads();
+  for (int e = tid; e < pool; e += 256) {
+    unsigned key, idx;
+    element(e, key, idx);
+    if (key < T || (key == T && idx <= I)) {
+      const int slot = atomicAdd(&fill, 1);
+      if (slot < k) sel[slot] = make_uint2(key, idx);
+    }
+  }
+  __syncthreads();  // the running list has been read for the last time: it may now be overwritten
+  const int got = fill < k ? fill : k;  // == need
+  for (int j = tid; j < k; j += 256) {
+    if (j >= got) {
+      rd[j] = INFINITY;
+      ri[j] = -1;
+    }
+  }
+  for (int j = tid; j < got; j += 256) {
+    const uint2 me = sel[j];
+    int rank = 0;
+    for (int i = 0; i < got; ++i) {
+      const uint2 o = sel[i];  // same address in every lane: LDS broadcast
+      rank += (o.x < me.x || (o.x == me.x && o.y < me.y)) ? 1 : 0;
+    }
+    const bool empty = me.y >= kEmptyIdx;
+    rd[rank] = empty ? INFINITY : __uint_as_float(me.x);
+    ri[rank] = empty ? -1 : (int)me.y;
+  }
+}
+
+// Final pass for k > 64: a workgroup per row, a wave per candidate for the exact distance, then a rank sort in LDS.
+__global__ __launch_bounds__(256) void knn_feat_finalize_large_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ y,
+                                                                      const int* __restrict__ run_i, int N, int M, int C,
+                                                                      int k, int kout, int64_t index_offset,
+                                                                      float* __restrict__ out_d,
+                                                                      int64_t* __restrict__ out_i) {
+  extern __shared__ uint2 sel[];  // (exact distance bits, index)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / N);
+  const float* xr = x + row * C;
+  for (int j = wave; j < k; j += 4) {
+    const int ij = run_i[row * k + j];  // wave-uniform
+    float dist = INFINITY;
+    if (ij >= 0) {
+      const float* yr = y + ((int64_t)b * M + ij) * C;
+      float part = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float df = xr[c] - yr[c];
+        part = __builtin_fmaf(df, df, part);
+      }
+      dist = sqrtf(wave_sum_f32(part));
+    }
+    if (lane == 0) sel[j] = make_uint2(__float_as_uint(dist), ij < 0 ? kEmptyIdx + (unsigned)j : (unsigned)ij);
+  }
+  __syncthreads();
+  for (int j = tid; j < k; j += 256) {
+    const uint2 me = sel[j];
+    const float md = __uint_as_float(me.x);
+    int rank = 0;
+    for (int i = 0; i < k; ++i) {
+      const uint2 o = sel[i];
+      const float od = __uint_as_float(o.x);
+      const bool o_real = o.y < kEmptyIdx, m_real = me.y < kEmptyIdx;
+      bool before;
+      if (o_real != m_real) before = o_real;
+      else before = od < md || (od == md && o.y < me.y);
+      rank += before ? 1 : 0;
+    }
+    if (rank < kout) {
+      out_d[row * kout + rank] = md;
+      out_i[row * kout + rank] = me.y < kEmptyIdx ? (int64_t)me.y + index_offset : (int64_t)-1;
     }
   }
 }
@@ -563,11 +728,14 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
   using namespace v3d;
   const char* what = "knn_feat";
   V3D_REQUIRE(batch >= 0 && N >= 0 && M >= 0 && C >= 0 && k >= 0, what, "negative dimension");
-  V3D_REQUIRE(k <= 64, what, "k must be <= 64");
+  if (k > V3D_KNN_FEAT_MAX_K) {
+    set_last_error("%s: k=%d exceeds %d", what, k, V3D_KNN_FEAT_MAX_K);
+    return V3D_ERR_K_TOO_LARGE;
+  }
   if (batch == 0 || N == 0 || k == 0) return 0;
   V3D_REQUIRE(x && distances && indices && (M == 0 || y), what, "null pointer");
-  if (batch > kMaxGridYZ || ceil_div(N, PD_BM) > kMaxGridYZ) {
-    set_last_error("%s: batch <= 65535 and N <= 8388480 required", what);
+  if (batch > kMaxGridYZ || ceil_div(N, PD_BM) > kMaxGridYZ || (int64_t)batch * N > 0x7fffffffll) {
+    set_last_error("%s: batch <= 65535, N <= 8388480 and batch * N < 2^31 required", what);
     return V3D_ERR_SIZE_LIMIT;
   }
   DeviceGuard guard(device);
@@ -590,11 +758,17 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
   KnnFeatWorkspace ws = carve_knn_ws(base, batch, N, Mw, k);
   int rc = 0;
   const unsigned row_blocks = (unsigned)ceil_div(rows, 4);
-  if (M == 0) {
-    // no candidates: every slot is (inf, -1)
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(row_blocks), dim3(256), 0, stream, ws.chunk, rows, 0, (int64_t)ws.mc, 0,
-                       k, 1, ws.run_d, ws.run_i);
-  }
+  const bool large = kout > 64;  // a workgroup per row instead of a wave per row
+  const size_t sel_bytes = sizeof(uint2) * (size_t)k;
+  auto select_rows = [&](int ncols, int col_base, int first) {
+    if (large)
+      hipLaunchKernelGGL(topk_rows_large_kernel, dim3((unsigned)rows), dim3(256), sel_bytes, stream, ws.chunk, ncols,
+                         (int64_t)ws.mc, col_base, k, first, ws.run_d, ws.run_i);
+    else
+      hipLaunchKernelGGL(topk_rows_kernel, dim3(row_blocks), dim3(256), 0, stream, ws.chunk, rows, ncols,
+                         (int64_t)ws.mc, col_base, k, first, ws.run_d, ws.run_i);
+  };
+  if (M == 0) select_rows(0, 0, 1);  // no candidates: every slot is (inf, -1)
   for (int m0 = 0; m0 < M && rc == 0; m0 += ws.mc) {
     const int mc = std::min(ws.mc, M - m0);
     // distances of every row of every batch against columns [m0, m0+mc): batch b uses y + (b*M + m0)*C
@@ -602,14 +776,17 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
     // only mc columns are visited per cloud, but consecutive clouds of y stay M*C apart
     rc = launch_pairwise(x, ychunk, ws.chunk, batch, N, mc, C, (int64_t)M * C, (int64_t)ws.mc, 0, 0.f, stream);
     if (rc) break;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(row_blocks), dim3(256), 0, stream, ws.chunk, rows, mc, (int64_t)ws.mc,
-                       m0, k, m0 == 0 ? 1 : 0, ws.run_d, ws.run_i);
+    select_rows(mc, m0, m0 == 0 ? 1 : 0);
     rc = launch_status(what);
   }
   if (rc == 0) {
     const int vec4 = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
-    hipLaunchKernelGGL(knn_feat_finalize_kernel, dim3(row_blocks), dim3(256), 0, stream, x, y, ws.run_d, ws.run_i,
-                       batch, N, Mw, C, k, kout, index_offset, vec4, distances, indices);
+    if (large)
+      hipLaunchKernelGGL(knn_feat_finalize_large_kernel, dim3((unsigned)rows), dim3(256), sel_bytes, stream, x, y,
+                         ws.run_i, N, Mw, C, k, kout, index_offset, distances, indices);
+    else
+      hipLaunchKernelGGL(knn_feat_finalize_kernel, dim3(row_blocks), dim3(256), 0, stream, x, y, ws.run_d, ws.run_i,
+                         batch, N, Mw, C, k, kout, index_offset, vec4, distances, indices);
     rc = launch_status(what);
   }
   if (own) {

@@ -824,21 +824,95 @@ __device__ void knn_exact_replay(const T* __restrict__ s_cloud, int N, int k, T 
   }
 }
 
+// ---- pack mode (ops/knn.py:110-145): clouds of different sizes concatenated ------------------------------------------
+// The reference pads every cloud to the longest with points at 1e10 and searches the padded batch; here a workgroup
+// serves 16 consecutive queries of ONE cloud against that cloud's own supports.  A one-workgroup kernel turns the two
+// length vectors into a plan (offsets + the first workgroup of every cloud; device side, no host synchronisation); the
+// search kernels are the batch kernels with the cloud looked up in the plan instead of blockIdx.y.
+struct KnnPackPlan {
+  long long q_off, s_off;
+  int q_len, s_len, wg_first, pad_;
+};
+
+__global__ __launch_bounds__(64) void knn_pack_plan_kernel(const int64_t* __restrict__ q_lengths,
+                                                           const int64_t* __restrict__ s_lengths,
+                                                           KnnPackPlan* __restrict__ plan, int B, long long total_q,
+                                                           long long total_s, int queries_per_wg) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long qo = 0, so = 0;
+  int wg = 0;
+  for (int b = 0; b <= B; ++b) {
+    // lengths that overrun the totals are cut (the caller promised they sum to the totals): no access leaves the arrays
+    long long ql = b < B ? (long long)q_lengths[b] : 0, sl = b < B ? (long long)s_lengths[b] : 0;
+    ql = ql < 0 ? 0 : (ql > total_q - qo ? total_q - qo : ql);
+    sl = sl < 0 ? 0 : (sl > total_s - so ? total_s - so : sl);
+    KnnPackPlan p;
+    p.q_off = qo;
+    p.s_off = so;
+    p.q_len = (int)ql;
+    p.s_len = (int)sl;
+    p.wg_first = wg;
+    p.pad_ = 0;
+    plan[b] = p;
+    qo += ql;
+    so += sl;
+    wg += (int)((ql + queries_per_wg - 1) / queries_per_wg);
+  }
+}
+
+struct KnnWhere {
+  int M, N, blk;           // queries / supports of the cloud, this workgroup's position among the cloud's workgroups
+  int64_t q_row0, s_row0;  // first query / support row of the cloud
+  bool live;
+};
+template <bool PACK>
+__device__ __forceinline__ KnnWhere knn_where(int M, int N, const KnnPackPlan* __restrict__ plan, int B) {
+  KnnWhere w;
+  if constexpr (!PACK) {
+    w.M = M;
+    w.N = N;
+    w.blk = blockIdx.x;
+    w.q_row0 = (int64_t)blockIdx.y * M;
+    w.s_row0 = (int64_t)blockIdx.y * N;
+    w.live = true;
+  } else {
+    const int id = blockIdx.x;
+    w.live = id < plan[B].wg_first;
+    // last cloud whose first workgroup is <= id: clouds without queries own no workgroup and share their start with the
+    // next cloud, which the bisection then prefers
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (plan[mid].wg_first <= id) lo = mid; else hi = mid;
+    }
+    const KnnPackPlan p = plan[lo];
+    w.M = p.q_len;
+    w.N = p.s_len;
+    w.blk = id - p.wg_first;
+    w.q_row0 = p.q_off;
+    w.s_row0 = p.s_off;
+  }
+  return w;
+}
+
 // Fast path: one wave serves QPW queries against LDS-staged supports.  Per query the k+1 best so far sit sorted in a
 // lane-distributed list; a chunk of 64 supports is filtered with one compare + ballot against the (k+1)-th best and
 // only the survivors are inserted (whole-wave DPP shift).  When the final k+1 distances are pairwise different the
 // reference heap can only produce this very list; otherwise the query is replayed through the exact heap.
-template <typename T, int R, int QPW, int TS>
+template <typename T, int R, int QPW, int TS, bool PACK = false>
 __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __restrict__ q, const T* __restrict__ s,
                                                                    T* __restrict__ out_d, int64_t* __restrict__ out_i,
-                                                                   int M, int N, int k) {
+                                                                   int M_arg, int N_arg, int k,
+                                                                   const KnnPackPlan* __restrict__ plan, int B) {
   __shared__ __align__(16) T tile[TS * 3];
   __shared__ HeapSlot<T> heaps[kWavesPerBlock * V3D_KNN_MAX_K];
-  const int b = blockIdx.y;
+  const KnnWhere where = knn_where<PACK>(M_arg, N_arg, plan, B);
+  if (!where.live) return;  // the whole workgroup
+  const int M = where.M, N = where.N;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q_first = (blockIdx.x * kWavesPerBlock + wave) * QPW;
-  const T* s_cloud = s + (int64_t)b * N * 3;
+  const int q_first = (where.blk * kWavesPerBlock + wave) * QPW;
+  const T* s_cloud = s + where.s_row0 * 3;
   const T sentinel = static_cast<T>(1e10);  // knn_points_cuda.cuh:71: nothing >= 1e10 ever enters
 
   T qx[QPW], qy[QPW], qz[QPW], tau[QPW], capk[QPW];
@@ -847,7 +921,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
   for (int g = 0; g < QPW; ++g) {
     const int qi = q_first + g;
     const bool live = qi < M;
-    const T* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
+    const T* qp = q + (where.q_row0 + (live ? qi : 0)) * 3;
     qx[g] = qp[0];
     qy[g] = qp[1];
     qz[g] = qp[2];
@@ -925,8 +999,8 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
 #pragma unroll
   for (int g = 0; g < QPW; ++g) {
     if (q_first + g >= M) continue;
-    T* od = out_d + ((int64_t)b * M + q_first + g) * k;
-    int64_t* oi = out_i + ((int64_t)b * M + q_first + g) * k;
+    T* od = out_d + (where.q_row0 + q_first + g) * k;
+    int64_t* oi = out_i + (where.q_row0 + q_first + g) * k;
     // equal real distances among ranks 0..k -> the heap's mechanics matter
     unsigned long long ties = 0ull;
     T prev_last = static_cast<T>(-1);
@@ -957,20 +1031,23 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
 // ascending across the lanes; survivors of the filter are compacted into a 64-slot LDS buffer per (wave, query) and a
 // full buffer -- or the last, partial one -- is merged by a bitonic network (wave_sort.h) instead of one whole-wave
 // insertion per survivor.  A survivor admitted against a stale bound is dropped by the merge, so the list is the same.
-template <int QPW, int TS>
+template <int QPW, int TS, bool PACK = false>
 __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const float* __restrict__ q,
                                                                          const float* __restrict__ s,
                                                                          float* __restrict__ out_d,
-                                                                         int64_t* __restrict__ out_i, int M, int N,
-                                                                         int k) {
+                                                                         int64_t* __restrict__ out_i, int M_arg,
+                                                                         int N_arg, int k,
+                                                                         const KnnPackPlan* __restrict__ plan, int B) {
   __shared__ __align__(16) float tile[TS * 3];
   __shared__ HeapSlot<float> heaps[kWavesPerBlock * V3D_KNN_MAX_K];
   __shared__ wkey_t hits[kWavesPerBlock][QPW][64];
-  const int b = blockIdx.y;
+  const KnnWhere where = knn_where<PACK>(M_arg, N_arg, plan, B);
+  if (!where.live) return;  // the whole workgroup
+  const int M = where.M, N = where.N;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q_first = (blockIdx.x * kWavesPerBlock + wave) * QPW;
-  const float* s_cloud = s + (int64_t)b * N * 3;
+  const int q_first = (where.blk * kWavesPerBlock + wave) * QPW;
+  const float* s_cloud = s + where.s_row0 * 3;
   const float sentinel = 1e10f;  // knn_points_cuda.cuh:71: nothing >= 1e10 ever enters
   const wkey_t sent_key = (wkey_t)__float_as_uint(sentinel) << 32;  // (1e10, index 0): the reference's empty slot
 
@@ -981,7 +1058,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
   for (int g = 0; g < QPW; ++g) {
     const int qi = q_first + g;
     const bool live = qi < M;
-    const float* qp = q + ((int64_t)b * M + (live ? qi : 0)) * 3;
+    const float* qp = q + (where.q_row0 + (live ? qi : 0)) * 3;
     qx[g] = qp[0];
     qy[g] = qp[1];
     qz[g] = qp[2];
@@ -1046,8 +1123,8 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
   for (int g = 0; g < QPW; ++g) {
     if (q_first + g >= M) continue;
     if (pending[g] > 0) kept[g] = wave_merge_buffer(kept[g], hits[wave][g], pending[g], lane);
-    float* od = out_d + ((int64_t)b * M + q_first + g) * k;
-    int64_t* oi = out_i + ((int64_t)b * M + q_first + g) * k;
+    float* od = out_d + (where.q_row0 + q_first + g) * k;
+    int64_t* oi = out_i + (where.q_row0 + q_first + g) * k;
     const float d = __uint_as_float((unsigned)(kept[g] >> 32));
     const float below = shr1_fill(d, -1.0f);
     // equal real distances among ranks 0..k -> the heap's mechanics matter
@@ -1085,20 +1162,89 @@ static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, 
   if constexpr (std::is_same<T, float>::value) {
     // batched survivors + bitonic merge: 14-25 % faster than the list from k ~ 24 up, slower below k ~ 12
     if (k >= 24 && k + 1 <= 64) {
-      hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
+      hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0);
       return launch_status(what);
     }
   }
   if (k + 1 <= 64)  // the list holds the k+1 best: one or two entries per lane
-    hipLaunchKernelGGL((knn_points_kernel<T, 1, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
+    hipLaunchKernelGGL((knn_points_kernel<T, 1, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0);
   else
-    hipLaunchKernelGGL((knn_points_kernel<T, 2, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k);
+    hipLaunchKernelGGL((knn_points_kernel<T, 2, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0);
   return launch_status(what);
+}
+
+constexpr int kKnnPackMaxClouds = 1 << 20;
+
+static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, const int64_t* s_lengths, float* od,
+                    int64_t* oi, int B, int64_t total_q, int64_t total_s, int k, void* workspace,
+                    size_t workspace_bytes, int device, void* stream_) {
+  const char* what = "knn_pack_mode";
+  V3D_REQUIRE(B >= 0 && total_q >= 0 && total_s >= 0 && k >= 0, what, "negative dimension");
+  if (k > V3D_KNN_MAX_K) {
+    set_last_error("%s: k=%d exceeds %d", what, k, V3D_KNN_MAX_K);
+    return V3D_ERR_K_TOO_LARGE;
+  }
+  if (total_q == 0 || k == 0) return 0;
+  V3D_REQUIRE(B > 0, what, "points without clouds");
+  V3D_REQUIRE(q && od && oi && q_lengths && s_lengths && (total_s == 0 || s), what, "null pointer");
+  constexpr int QPW = 4;
+  constexpr int TS = 1024;
+  constexpr int kPerWg = kWavesPerBlock * QPW;
+  if (B > kKnnPackMaxClouds || total_s > (int64_t)INT32_MAX || ceil_div(total_q, kPerWg) + B > (int64_t)INT32_MAX) {
+    set_last_error("%s: at most 2^20 clouds, 2^31-1 supports and 2^35 queries per call", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const size_t need = v3d_knn_pack_workspace_bytes(B);
+  void* base = workspace;
+  bool own = false;
+  if (base == nullptr) {
+    V3D_HIP_TRY(hipMallocAsync(&base, need, stream), what);
+    own = true;
+  } else if (workspace_bytes < need || ((uintptr_t)base & 255) != 0) {
+    set_last_error("%s: workspace needs %zu bytes, 256-B aligned (got %zu)", what, need, workspace_bytes);
+    return V3D_ERR_WORKSPACE;
+  }
+  KnnPackPlan* plan = static_cast<KnnPackPlan*>(base);
+  hipLaunchKernelGGL(knn_pack_plan_kernel, dim3(1), dim3(64), 0, stream, q_lengths, s_lengths, plan, B,
+                     (long long)total_q, (long long)total_s, kPerWg);
+  // every cloud rounds its queries up to whole workgroups: at most one partly filled workgroup per cloud
+  dim3 grid((unsigned)(ceil_div(total_q, kPerWg) + B)), block(kQueryThreads);
+  if (k >= 24 && k + 1 <= 64)
+    hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS, true>), grid, block, 0, stream, q, s, od, oi, 0, 0, k, plan, B);
+  else if (k + 1 <= 64)
+    hipLaunchKernelGGL((knn_points_kernel<float, 1, QPW, TS, true>), grid, block, 0, stream, q, s, od, oi, 0, 0, k, plan,
+                       B);
+  else
+    hipLaunchKernelGGL((knn_points_kernel<float, 2, QPW, TS, true>), grid, block, 0, stream, q, s, od, oi, 0, 0, k, plan,
+                       B);
+  int rc = launch_status(what);
+  if (own) {
+    hipError_t e = hipFreeAsync(base, stream);
+    if (rc == 0 && e != hipSuccess) {
+      set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
+      rc = (int)e;
+    }
+  }
+  return rc;
 }
 
 }  // namespace v3d
 
 extern "C" {
+
+size_t v3d_knn_pack_workspace_bytes(int B) {
+  return B < 0 ? 0 : v3d::align_up(sizeof(v3d::KnnPackPlan) * ((size_t)B + 1), 256);
+}
+
+int v3d_knn_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
+                     float* distances, int64_t* indices, int B, int64_t total_q, int64_t total_s, int k,
+                     void* workspace, size_t workspace_bytes, int device, void* stream) {
+  return v3d::knn_pack(q_points, s_points, q_lengths, s_lengths, distances, indices, B, total_q, total_s, k, workspace,
+                       workspace_bytes, device, stream);
+}
 
 int v3d_ball_query_f32(const float* q, const float* s, int64_t* indices, int B, int M, int N, float max_radius, int k,
                        int device, void* stream) {

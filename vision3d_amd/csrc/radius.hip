@@ -14,7 +14,7 @@
 //   3. rs_query_*        : one WAVE per query.  The 27 neighbouring cells are 9 contiguous runs of records (cells are
 //                          x-major) whose bounds lanes 0..8 fetch in one round trip; 64 lanes test 64 candidates of the
 //                          concatenated runs at once.  limit <= 64: hits are batched in LDS as 64-bit (d2, index) keys
-//                          and merged into the kept list by a bitonic network; limit <= 128: lane-distributed sorted
+//                          and merged into the kept list by a bitonic network; limit <= 512: lane-distributed sorted
 //                          list with a whole-wave DPP shift per hit.  rs_count_query: popcount of the hits.
 //                          The result does not depend on the order candidates arrive in.
 // Distances use the reference expression order (dx*dx + dy*dy) + dz*dz with one rounding per operation.
@@ -487,8 +487,8 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
   V3D_REQUIRE(q_points && q_lengths && s_lengths && neighbor_indices && (total_s == 0 || s_points), what,
               "null pointer");
   V3D_REQUIRE(radius >= 0.f, what, "negative radius");  // NaN fails too
-  if (neighbor_limit > 128) {
-    set_last_error("%s: neighbor_limit=%d exceeds 128", what, neighbor_limit);
+  if (neighbor_limit > V3D_RADIUS_MAX_LIMIT) {
+    set_last_error("%s: neighbor_limit=%d exceeds %d", what, neighbor_limit, V3D_RADIUS_MAX_LIMIT);
     return V3D_ERR_K_TOO_LARGE;
   }
   if (B > kRsMaxClouds || total_s >= (int64_t)INT32_MAX - 1 ||
@@ -550,8 +550,16 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
       hipLaunchKernelGGL(rs_query_sort_kernel, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
                          ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
                          neighbor_limit);
-    else
+    else if (neighbor_limit <= 128)
       hipLaunchKernelGGL(rs_query_kernel<2>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
+                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
+                         neighbor_limit);
+    else if (neighbor_limit <= 256)
+      hipLaunchKernelGGL(rs_query_kernel<4>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
+                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
+                         neighbor_limit);
+    else
+      hipLaunchKernelGGL(rs_query_kernel<8>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
                          ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
                          neighbor_limit);
     rc = launch_status(what);

@@ -386,6 +386,32 @@ def radius_search_pack(q_points, s_points, q_lengths, s_lengths, neighbor_indice
     _lib.check(rc, "radius_search_pack_mode")
 
 
+def knn_pack(q_points, s_points, q_lengths, s_lengths, distances, indices, num_neighbors):
+    """q_points (M,3), s_points (N,3) fp32; lengths (B,) int64 on the same device -> distances (M,k) fp32, indices (M,k)
+    int64 = positions inside the query's own cloud.  k <= 100 (the knn_points kernels)."""
+    for t, name in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"), (s_lengths, "s_lengths"),
+                    (distances, "distances"), (indices, "indices")):
+        _check_cuda_contiguous(t, name)
+    for t, name in ((q_points, "q_points"), (s_points, "s_points"), (distances, "distances")):
+        _check_float(t, name)
+    for t, name in ((q_lengths, "q_lengths"), (s_lengths, "s_lengths"), (indices, "indices")):
+        _check_long(t, name)
+    B = q_lengths.shape[0]
+    if s_lengths.shape[0] != B:
+        raise RuntimeError("q_lengths and s_lengths must have the same number of clouds")
+    M, N, k = q_points.shape[0], s_points.shape[0], int(num_neighbors)
+    if q_points.shape[-1] != 3 or s_points.shape[-1] != 3:
+        raise RuntimeError("knn_pack: points must be (N, 3)")
+    if distances.numel() != M * k or indices.numel() != M * k:
+        raise RuntimeError("knn_pack: distances / indices must hold k entries per query")
+    dev, stream = _where(q_points)
+    ws = _workspace(_lib.lib().v3d_knn_pack_workspace_bytes(B), q_points)
+    rc = _lib.lib().v3d_knn_pack_f32(
+        q_points.data_ptr(), s_points.data_ptr(), q_lengths.data_ptr(), s_lengths.data_ptr(), distances.data_ptr(),
+        indices.data_ptr(), B, M, N, k, ws.data_ptr(), ws.numel(), dev, stream)
+    _lib.check(rc, "knn_pack_mode")
+
+
 def radius_count_pack(q_points, s_points, q_lengths, s_lengths, counts, radius):
     """q_points (M,3), s_points (N,3) fp32; lengths (B,) int64 on the same device; counts (M,) int64."""
     for t, name in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"),
@@ -836,19 +862,29 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lenghts, radius):
     (csrc/cpu/radius_neighbors/radius_neighbors.cpp:5-93; keyword `s_lenghts` as registered, pybind.cpp:41).
 
     Differences: points AT the radius are included (the GPU path follows ops/radius_search.py:66, the CPU code's nanoflann
-    search is strict), and a query with more than 128 neighbours raises instead of widening the table."""
+    search is strict), and the table is at most 512 wide (the search kernel's list): a query with 512 or more neighbours
+    raises instead of widening it further."""
     import numpy as np
 
     q, s = _np_to_dev(q_points, np.float32), _np_to_dev(s_points, np.float32)
     ql, sl = _np_to_dev(q_lengths, np.int64), _np_to_dev(s_lenghts, np.int64)
-    limit = 128
-    out = torch.empty((q.shape[0], limit), dtype=torch.long, device=q.device)
-    radius_search_pack(q, s, ql, sl, out, float(radius), limit)
-    counts = (out != s.shape[0]).sum(dim=1)
-    widest = int(counts.max().item()) if q.shape[0] else 0
-    if widest >= limit:
-        raise RuntimeError("radius_neighbors: a query has 128 or more neighbours; use radius_search_pack_mode with a limit")
-    return out[:, :widest].cpu().numpy()
+    if q.shape[0] == 0:
+        return np.zeros((0, 0), dtype=np.int64)
+    counts = torch.empty((q.shape[0],), dtype=torch.long, device=q.device)
+    radius_count_pack(q, s, ql, sl, counts, float(radius))
+    widest = int(counts.max().item())  # strict count; supports exactly AT the radius come on top of it
+    filled = limit = 0
+    for limit in (64, 128, 512):
+        if widest >= limit and limit < 512:
+            continue
+        out = torch.empty((q.shape[0], limit), dtype=torch.long, device=q.device)
+        radius_search_pack(q, s, ql, sl, out, float(radius), limit)
+        filled = int((out != s.shape[0]).sum(dim=1).max().item())
+        if filled < limit:
+            break
+    if filled >= limit:
+        raise RuntimeError("radius_neighbors: a query has 512 or more neighbours; use radius_search_pack_mode with a limit")
+    return out[:, :filled].cpu().numpy()
 
 
 def grid_subsampling(points, lengths, voxel_size):

@@ -1,10 +1,16 @@
-"""Feature-space / general kNN -- mirrors ``vision3d/ops/knn.py:30-145`` (``knn``, ``knn_pack_mode``).
+"""Feature-space / general kNN -- the interface of ``vision3d/ops/knn.py:30-145`` (``knn``, ``knn_pack_mode``).
 
 The reference delegates the search to pykeops (``keops_knn``, knn.py:10-27: k smallest Euclidean distances,
 ascending, with their indices).  pykeops is a third-party JIT library absent from this build, so the search is
-re-backed by our own kernels: 3-D points go through the exact-difference ``knn_points`` kernel, other channel
-counts through the MFMA distance + top-k kernels (``ext.knn_feat``).  Post-processing (dilation,
-remove_nearest, distance_limit padding, squeeze) follows the reference line by line in meaning.
+re-backed by our own kernels:
+
+* 3-D fp32/fp64 points, k <= 100: the exact-difference ``knn_points`` kernels;
+* any other channel count or larger k (<= 2048): MFMA distances + row selection + exact re-ranking (``ext.knn_feat``);
+* pack mode (3-D fp32, k <= 100): the same ``knn_points`` kernels working on each cloud's own slice of the packed arrays
+  (``ext.knn_pack``) -- no padded batch, no ``.item()``.
+
+``knn``'s options (dilation, remove_nearest, distance_limit / padding_mode, squeeze; reference knn.py:43-63) are expressed
+as ONE strided column selection of the ascending list plus one masked fill.
 """
 from typing import Tuple
 
@@ -14,25 +20,32 @@ from torch import Tensor
 from .. import ext
 from .conversion import batch_to_pack, pack_to_batch
 
+_KNN_POINTS_MAX_K = 100  # knn_points_cuda.cuh:68 (best_dist[100]); kept by our kernels
+_KNN_FEAT_MAX_K = 2048  # include/v3d_hip.h: V3D_KNN_FEAT_MAX_K
+
 
 def keops_knn(q_points: Tensor, s_points: Tensor, k: int) -> Tuple[Tensor, Tensor]:
-    """(*, N, C), (*, M, C) -> distances (*, N, k) ascending, indices (*, N, k).  Name kept for drop-in use."""
+    """(*, N, C), (*, M, C) -> distances (*, N, k) ascending, indices (*, N, k).  Name kept for drop-in use.
+
+    pykeops has no limit on k; here k <= 2048 (k > M yields (inf, -1) in the extra slots of the feature path)."""
     if not (q_points.is_cuda and s_points.is_cuda):
         raise RuntimeError("knn: q_points and s_points must be CUDA tensors (no CPU fallback in vision3d_amd)")
     if q_points.dtype != torch.float32 or s_points.dtype != torch.float32:
         raise RuntimeError("knn: q_points and s_points must be float tensors")
-    lead = q_points.shape[:-2]
+    if k > _KNN_FEAT_MAX_K:
+        raise RuntimeError(f"knn: k={k} exceeds {_KNN_FEAT_MAX_K}, the largest list the selection kernels keep per query")
+    lead = tuple(q_points.shape[:-2])
     n, c = q_points.shape[-2:]
     m = s_points.shape[-2]
     qb = q_points.reshape((-1, n, c)).contiguous()
     sb = s_points.reshape((-1, m, c)).contiguous()
     dist = qb.new_empty((qb.shape[0], n, k))
     idx = torch.empty((qb.shape[0], n, k), dtype=torch.long, device=qb.device)
-    if c == 3 and k <= 100:
+    if c == 3 and k <= _KNN_POINTS_MAX_K:
         ext.knn_points(qb, sb, dist, idx, k)
     else:
         ext.knn_feat(qb, sb, dist, idx, k)
-    return dist.reshape(tuple(lead) + (n, k)), idx.reshape(tuple(lead) + (n, k))
+    return dist.reshape(lead + (n, k)), idx.reshape(lead + (n, k))
 
 
 def knn(
@@ -50,47 +63,36 @@ def knn(
 ):
     """kNN of ``q_points`` in ``s_points`` ((*, N, C) / (*, M, C), channel-first if ``transposed``).
 
-    Returns indices (*, N, k), preceded by distances if ``return_distance``; see reference knn.py:43-63 for the
-    meaning of dilation / distance_limit / padding_mode / remove_nearest / squeeze.
+    Returns indices (*, N, k), preceded by distances if ``return_distance``.  Of the ascending neighbour list the ranks
+    ``first, first + dilation, ...`` are kept, ``first`` = 1 with ``remove_nearest`` (drop the query itself) else 0; the
+    list is as long as that needs, cut at the number of supports.  Neighbours at or beyond ``distance_limit`` are replaced
+    by the nearest one (``padding_mode="nearest"``) or by ``(padding_value, M)`` (``"empty"``).
     """
     if transposed:
-        q_points = q_points.transpose(-1, -2)
-        s_points = s_points.transpose(-1, -2)
-    q_points = q_points.contiguous()
-    s_points = s_points.contiguous()
-    num_s_points = s_points.shape[-2]
-
-    dilated_k = (k - 1) * dilation + 1
-    if remove_nearest:
-        dilated_k += 1
-    final_k = min(dilated_k, num_s_points)
-    knn_distances, knn_indices = keops_knn(q_points, s_points, final_k)
-
-    if remove_nearest:
-        knn_distances = knn_distances[..., 1:]
-        knn_indices = knn_indices[..., 1:]
-    if dilation > 1:
-        knn_distances = knn_distances[..., ::dilation]
-        knn_indices = knn_indices[..., ::dilation]
-    knn_distances = knn_distances.contiguous()
-    knn_indices = knn_indices.contiguous()
+        q_points, s_points = q_points.transpose(-1, -2), s_points.transpose(-1, -2)
+    q_points, s_points = q_points.contiguous(), s_points.contiguous()
+    num_supports = s_points.shape[-2]
+    first = 1 if remove_nearest else 0
+    searched = min(first + (k - 1) * dilation + 1, num_supports)
+    distances, indices = keops_knn(q_points, s_points, searched)
+    if first or dilation > 1:
+        distances, indices = distances[..., first::dilation], indices[..., first::dilation]
+    distances, indices = distances.contiguous(), indices.contiguous()
 
     if distance_limit is not None:
         assert padding_mode in ["nearest", "empty"]
-        too_far = torch.ge(knn_distances, distance_limit)
+        beyond = distances >= distance_limit
         if padding_mode == "nearest":
-            knn_distances = torch.where(too_far, knn_distances[..., :1], knn_distances)
-            knn_indices = torch.where(too_far, knn_indices[..., :1], knn_indices)
+            fill_distance, fill_index = distances[..., :1], indices[..., :1]
         else:
-            knn_distances[too_far] = padding_value
-            knn_indices[too_far] = num_s_points
+            fill_distance = distances.new_full((), padding_value)
+            fill_index = indices.new_full((), num_supports)
+        distances = torch.where(beyond, fill_distance, distances)
+        indices = torch.where(beyond, fill_index, indices)
 
     if squeeze and k == 1:
-        knn_distances = knn_distances.squeeze(-1)
-        knn_indices = knn_indices.squeeze(-1)
-    if return_distance:
-        return knn_distances, knn_indices
-    return knn_indices
+        distances, indices = distances.squeeze(-1), indices.squeeze(-1)
+    return (distances, indices) if return_distance else indices
 
 
 def knn_pack_mode(
@@ -102,13 +104,32 @@ def knn_pack_mode(
     return_distance: bool = False,
     inf: float = 1e10,
 ):
-    """kNN in pack mode: q_points (N, 3), s_points (M, 3) with per-cloud lengths (B,) -> (N, k) per-cloud indices."""
+    """kNN in pack mode: q_points (N, 3), s_points (M, 3) with per-cloud lengths (B,) -> (N, k) indices INSIDE the cloud
+    (what the reference's padded batch yields, knn.py:138-141), preceded by the distances if ``return_distance``.
+
+    The length check is the reference's own assertion (knn.py:137; one boolean read back from the device, gone under
+    ``python -O``); the search itself neither pads nor synchronises.  ``inf`` only matters on the padded route taken by
+    inputs the pack kernel does not cover (not fp32 3-D, or k > 100)."""
     assert torch.all(torch.ge(s_lengths, k)), f"The number of support points less than {k}."
+    native = (q_points.is_cuda and q_points.dtype == torch.float32 and s_points.dtype == torch.float32
+              and q_points.dim() == 2 and q_points.shape[-1] == 3 and s_points.shape[-1] == 3 and k <= _KNN_POINTS_MAX_K)
+    if not native:
+        return padded_knn_pack_mode(q_points, s_points, q_lengths, s_lengths, k, return_distance, inf)
+    distances = q_points.new_empty((q_points.shape[0], k))
+    indices = torch.empty((q_points.shape[0], k), dtype=torch.long, device=q_points.device)
+    ext.knn_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.to(torch.long).contiguous(),
+                 s_lengths.to(torch.long).contiguous(), distances, indices, k)
+    return (distances, indices) if return_distance else indices
+
+
+def padded_knn_pack_mode(q_points, s_points, q_lengths, s_lengths, k, return_distance=False, inf=1e10):
+    """The reference's formulation (knn.py:138-145): pad every cloud to the longest with points at ``inf``, search the
+    batch, take the rows of the real queries."""
     batch_q_points, batch_q_masks = pack_to_batch(q_points, q_lengths, fill_value=inf)
     batch_s_points, _ = pack_to_batch(s_points, s_lengths, fill_value=inf)
-    batch_knn_distances, batch_knn_indices = keops_knn(batch_q_points, batch_s_points, k)
-    knn_indices, _ = batch_to_pack(batch_knn_indices, masks=batch_q_masks)
+    batch_distances, batch_indices = keops_knn(batch_q_points, batch_s_points, k)
+    indices, _ = batch_to_pack(batch_indices, masks=batch_q_masks)
     if not return_distance:
-        return knn_indices
-    knn_distances, _ = batch_to_pack(batch_knn_distances, masks=batch_q_masks)
-    return knn_distances, knn_indices
+        return indices
+    distances, _ = batch_to_pack(batch_distances, masks=batch_q_masks)
+    return distances, indices

@@ -14,10 +14,10 @@ def radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, ne
     """q_points (M, 3), s_points (N, 3), lengths (B,) -> neighbor indices (M, neighbor_limit), N where absent.
 
     Native pack-mode kernel (uniform-grid cell list, no padding, no host synchronisation).  fp32 3-D points with
-    ``neighbor_limit <= 128``; anything else takes the reference's route (kNN over padded batches + mask).  ``inf`` is
+    ``neighbor_limit <= 512``; anything else takes the reference's route (kNN over padded batches + mask).  ``inf`` is
     only used by that route."""
     if (q_points.dtype == torch.float32 and s_points.dtype == torch.float32 and q_points.shape[-1] == 3
-            and 0 < neighbor_limit <= 128):
+            and 0 < neighbor_limit <= 512):
         out = torch.empty((q_points.shape[0], neighbor_limit), dtype=torch.long, device=q_points.device)
         ext.radius_search_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.contiguous(),
                                s_lengths.contiguous(), out, radius, neighbor_limit)
