@@ -178,6 +178,13 @@ struct ChunkRegs {
   static constexpr int kVec = 16 / sizeof(T);
   static constexpr int kGroups = ChunkGeom<MODE>::P / kVec;            // 16-byte column groups per grad_out row
   static constexpr int kRows = CT * kGroups / kScatterThreads;         // rows (channels) a thread loads
+  static constexpr int kParts = CT / kRows;                            // threads that share one column group
+  // Column c's record (CT values) lives at slot swz(c): the low bits are XORed with the column-group number, so that
+  // the kVec-strided columns a wave stores together fall into different banks (records of 16 or 32 bytes at a stride
+  // of kVec records would otherwise hit 2-4 banks with all 64 lanes: measured 0.7 of the kernel's LDS-busy cycles).
+  static constexpr int kRecsPerBankCycle = 256 / (CT * (int)sizeof(T));
+  static constexpr int kVecShift = kVec == 4 ? 2 : 1;
+  __device__ static __forceinline__ int swz(int c) { return c ^ ((c >> kVecShift) & (kRecsPerBankCycle - 1)); }
   static constexpr int kEntVecs = ChunkGeom<MODE>::EMAX * 2 / 16;
   static constexpr int kEntV = (kEntVecs + kScatterThreads - 1) / kScatterThreads;
   static constexpr int kWVecs = ChunkGeom<MODE>::EMAX * (int)sizeof(T) / 16;
@@ -185,6 +192,8 @@ struct ChunkRegs {
   static constexpr int kSegMax = ChunkGeom<MODE>::EMAX < kMaxLdsSources ? ChunkGeom<MODE>::EMAX : kMaxLdsSources;
   static constexpr int kSeg = (kSegMax + kScatterThreads - 1) / kScatterThreads;  // segment slots per thread
   static_assert(kRows >= 1 && CT * kGroups % kScatterThreads == 0, "tile must split evenly over the workgroup");
+  static_assert(CT % kRows == 0 && kParts * kGroups == kScatterThreads && (kVec == 4 || kVec == 2), "thread -> tile piece map");
+  static_assert(ChunkGeom<MODE>::P % kRecsPerBankCycle == 0 && (kRecsPerBankCycle & (kRecsPerBankCycle - 1)) == 0, "swizzle");
   uint4 t[kRows];
   uint4 e[kEntV];
   uint4 w[kWV];
@@ -204,7 +213,6 @@ __global__ __launch_bounds__(kScatterThreads) void segment_sum_kernel_lds(
   constexpr int EMAX = ChunkGeom<MODE>::EMAX;
   constexpr int TH = kScatterThreads;
   constexpr int kVec = Regs::kVec;
-  constexpr int kGroups = Regs::kGroups;
   constexpr int kRows = Regs::kRows;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* acc = reinterpret_cast<T*>(smem_raw);
@@ -217,7 +225,10 @@ __global__ __launch_bounds__(kScatterThreads) void segment_sum_kernel_lds(
   const int c0 = bx * CT;
   for (int i = tid; i < N * CT; i += TH) acc[i] = T(0);
 
-  const int grp = tid % kGroups, part = tid / kGroups;  // this thread's tile piece: rows part*kRows .. +kRows-1
+  // this thread's tile piece: column group grp, rows part*kRows .. +kRows-1.  Neighbouring lanes take the parts of one
+  // column group (together one whole record per column), then the next group: with the slot swizzle the transposed
+  // stores below are free of bank conflicts, and a row is still read in runs of 64 / kParts adjacent 16-byte pieces.
+  const int part = tid % Regs::kParts, grp = tid / Regs::kParts;
 
 #define V3D_LOAD_CHUNK(r, kk)                                                                                   \
   do {                                                                                                          \
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(kScatterThreads) void segment_sum_kernel_lds(
     _Pragma("unroll") for (int e = 0; e < kVec; ++e) {                                                          \
       T piece[kRows];                                                                                           \
       _Pragma("unroll") for (int i = 0; i < kRows; ++i) piece[i] = reinterpret_cast<const T*>(&(r).t[i])[e];    \
-      T* dst = tile + (size_t)(grp * kVec + e) * CT + part * kRows;                                             \
+      T* dst = tile + (size_t)Regs::swz(grp * kVec + e) * CT + part * kRows;                                    \
       _Pragma("unroll") for (int i = 0; i < kRows; ++i) dst[i] = piece[i];                                      \
     }                                                                                                           \
     _Pragma("unroll") for (int i = 0; i < Regs::kEntV; ++i) {                                                   \
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(kScatterThreads) void segment_sum_kernel_lds(
         _Pragma("unroll") for (int c = 0; c < CT; ++c) a[c] = acc[(size_t)n * CT + c];                          \
         bool last;                                                                                              \
         do {                                                                                                    \
-          const T* tv = tile + (size_t)(en & 0x7FFFu) * CT;                                                     \
+          const T* tv = tile + (size_t)Regs::swz((int)(en & 0x7FFFu)) * CT;                                     \
           T x[CT];                                                                                              \
           _Pragma("unroll") for (int c = 0; c < CT; ++c) x[c] = tv[c];                                          \
           last = (en & 0x8000u) != 0;                                                                           \
