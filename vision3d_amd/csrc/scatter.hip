@@ -133,6 +133,9 @@ __global__ __launch_bounds__(kScatterThreads) void csr_chunk_build_kernel(
   int run = incl - sum;
   for (int q = 0; q < wave; ++q) run += wave_tot[q];
   uint32_t* sg = seg_g + ((int64_t)b * nchunks + k) * segs;
+  // (Ordering the segment list by length, longest first, so that a wave of the sum kernel runs segments of one length:
+  // measured 242 -> 217 us on the k = 128 sum kernel, but every way of computing the order here -- class counters with
+  // LDS atomics, per wave or per workgroup; ballots; counters packed through the scan -- cost this kernel 17 us or more.)
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int n = tid * kItems + i;
@@ -191,6 +194,7 @@ struct ChunkRegs {
   static constexpr int kWV = MODE == 1 ? (kWVecs + kScatterThreads - 1) / kScatterThreads : 1;
   static constexpr int kSegMax = ChunkGeom<MODE>::EMAX < kMaxLdsSources ? ChunkGeom<MODE>::EMAX : kMaxLdsSources;
   static constexpr int kSeg = (kSegMax + kScatterThreads - 1) / kScatterThreads;  // segment slots per thread
+  static constexpr int kDepth = 2;  // chunks in flight besides the one being summed (3 and 4 measured no faster)
   static_assert(kRows >= 1 && CT * kGroups % kScatterThreads == 0, "tile must split evenly over the workgroup");
   static_assert(CT % kRows == 0 && kParts * kGroups == kScatterThreads && (kVec == 4 || kVec == 2), "thread -> tile piece map");
   static_assert(ChunkGeom<MODE>::P % kRecsPerBankCycle == 0 && (kRecsPerBankCycle & (kRecsPerBankCycle - 1)) == 0, "swizzle");
@@ -315,31 +319,29 @@ __global__ __launch_bounds__(kScatterThreads) void segment_sum_kernel_lds(
     }                                                                                                           \
   } while (0)
 
-  // Two register sets, chunks k+2 and k+3 in flight while k and k+1 are summed.  The loop starts two chunks early
-  // (k = -2 only loads) so that each set is defined at ONE place: with a peeled prologue the register allocator
-  // joins the two definitions through copies at the loop latch, and a copy waits for the load it copies.
-  Regs ra, rb;
-  for (int k = -2; k < nchunks; k += 2) {  // an odd tail runs one empty half (no segments)
-    unsigned segv[Regs::kSeg];
-    if (k >= 0) {
-      __syncthreads();  // chunk k-1 consumed (first pass: acc zeroed)
-      V3D_STORE_CHUNK(ra);
+  // kDepth register sets: chunks k+1 .. k+kDepth are in flight while chunk k is summed (one workgroup fills a CU, so
+  // the loads in flight are all that hides the memory latency).  The loop starts kDepth chunks early (the first pass
+  // only loads) so that each set is defined at ONE place: with a peeled prologue the register allocator joins the two
+  // definitions through copies at the loop latch, and a copy waits for the load it copies.  Every set issues the same
+  // number of loads, oldest set first, so the wait before a store is a counted vmcnt that leaves the younger sets in
+  // flight.  A tail that is not a multiple of kDepth runs empty sets (no segments).
+  constexpr int kDepth = Regs::kDepth;
+  Regs r[kDepth];
+  for (int k = -kDepth; k < nchunks; k += kDepth) {
 #pragma unroll
-      for (int i = 0; i < Regs::kSeg; ++i) segv[i] = (i * TH + tid < segs) ? ra.s[i] : kNoSegment;
-      __syncthreads();
-    }
-    V3D_LOAD_CHUNK(ra, k + 2);
-    if (k >= 0) {
-      V3D_SUM_CHUNK(segv);
-      __syncthreads();
-      V3D_STORE_CHUNK(rb);
+    for (int j = 0; j < kDepth; ++j) {
+      unsigned segv[Regs::kSeg];
+      if (k >= 0) {
+        __syncthreads();  // chunk k+j-1 consumed (first pass: acc zeroed)
+        V3D_STORE_CHUNK(r[j]);
 #pragma unroll
-      for (int i = 0; i < Regs::kSeg; ++i)
-        segv[i] = (i * TH + tid < segs && k + 1 < nchunks) ? rb.s[i] : kNoSegment;
-      __syncthreads();
+        for (int i = 0; i < Regs::kSeg; ++i)
+          segv[i] = (i * TH + tid < segs && k + j < nchunks) ? r[j].s[i] : kNoSegment;
+        __syncthreads();
+      }
+      V3D_LOAD_CHUNK(r[j], k + j + kDepth);
+      if (k >= 0) V3D_SUM_CHUNK(segv);
     }
-    V3D_LOAD_CHUNK(rb, k + 3);
-    if (k >= 0) V3D_SUM_CHUNK(segv);
   }
 #undef V3D_LOAD_CHUNK
 #undef V3D_STORE_CHUNK
@@ -553,8 +555,16 @@ int scatter_backward(const char* what, const T* gout, const int64_t* idx, const 
       // acc[N][CT] + tile[P][CT] + lists must fit 160 KiB: 32-byte channel vectors up to 1024 sources, else 16-byte
       constexpr int kQuad = 16 / sizeof(T);
       bool wide = false;
+      if constexpr (sizeof(T) == 4 && MODE == 1) {
+        // interpolation (short target rows, few chunks per workgroup): 16 channels per workgroup halve the list reads
+        // and the per-entry bookkeeping, and C/16 x B workgroups fill the chip in one round at C2
+        if (N <= 1024 && C >= 16) {
+          wide = true;
+          rc = launch_chunked<T, MODE, 16>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
+        }
+      }
       if constexpr (sizeof(T) == 4) {
-        if (N <= 1024) {
+        if (!wide && N <= 1024) {
           wide = true;
           rc = launch_chunked<T, MODE, 8>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
         }
