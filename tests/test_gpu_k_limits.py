@@ -275,3 +275,56 @@ def test_knn_pack_lengths_that_overrun_the_arrays_are_cut(ext):
     ext.knn_pack(q, s, torch.tensor([60, 500], device=DEV), torch.tensor([50, 10 ** 9], device=DEV), d, i, 4)
     torch.cuda.synchronize()
     assert int(i[:60].max()) < 50 and int(i[60:].max()) < 30 and int(i.min()) >= 0
+
+
+def test_radius_neighbors_is_strict_at_the_radius(ext, oracle_mod):
+    """Lattice with spacing 0.25 and radius 0.25: the six axis neighbours sit exactly AT the radius; the NumPy entry
+    point mirrors the CPU code's strict nanoflann search (radius_neighbors.cpp), the search kernel itself is inclusive."""
+    pts = lattice_cloud(5, 0.25)[0].astype(np.float32)
+    lengths = np.asarray([pts.shape[0]], np.int64)
+    table = ext.radius_neighbors(pts, pts, lengths, lengths, 0.25)
+    strict = oracle_mod.radius_count_pack(pts, pts, lengths, lengths, 0.25)
+    assert table.shape[1] == strict.max() == 1  # only the point itself is strictly inside
+    assert np.array_equal(table[:, 0], np.arange(pts.shape[0]))
+    inclusive = oracle_mod.radius_search_pack(pts, pts, lengths, lengths, 0.25, 8)
+    assert (inclusive != pts.shape[0]).sum(axis=1).max() == 7
+
+
+def test_selected_scores_carry_gradients_like_the_reference_indexing(ext):
+    """mutual_topk_select.py:57 returns score_mat[rows, cols]: differentiable.  Same here when a gradient can be asked."""
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    score = torch.rand((40, 50), generator=g).to(DEV).requires_grad_(True)
+    rows, cols, vals = ops.mutual_topk_select(score, 2, largest=True)
+    assert vals.requires_grad and torch.equal(vals.detach(), score.detach()[rows, cols])
+    vals.sum().backward()
+    want = torch.zeros_like(score)
+    want[rows, cols] = 1.0
+    assert torch.equal(score.grad, want)
+    with torch.no_grad():
+        r2, c2, v2 = ops.mutual_topk_select(score, 2, largest=True)
+    assert not v2.requires_grad and torch.equal(r2, rows) and torch.equal(v2, vals.detach())
+
+
+def test_pairwise_distance_backward_blocks_exactly_the_clipped_cells(ext):
+    """clamp(min=0) (pairwise_distance.py:53): no gradient through cells the clamp clipped, with or without the sqrt."""
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((1, 64, 32), generator=g).to(DEV)
+    y = x.clone()
+    y[:, 32:] += 0.5 * torch.randn((1, 32, 32), generator=g).to(DEV)  # rows 0..31 coincide with x: d_raw ~ +-1e-6
+    for squared in (True, False):
+        xr = x.clone().requires_grad_(True)
+        out = ops.pairwise_distance(xr, y, squared=squared)
+        go = torch.ones_like(out)
+        (gx,) = torch.autograd.grad(out, xr, go)
+        floor = 0.0 if squared else float(torch.sqrt(torch.tensor(1e-8)))
+        clipped = out.detach() <= floor
+        assert clipped[0, :32, :32].diagonal().float().mean() > 0.2  # the coinciding pairs do clip
+        # reference formula with the same mask: d = |x|^2 - 2xy + |y|^2, grad_x = 2 (sum_m g) x - 2 g y
+        gm = torch.where(clipped, torch.zeros_like(go), go if squared else go / (2.0 * out.detach()))
+        want = 2.0 * (gm.sum(-1, keepdim=True) * x - torch.matmul(gm, y))
+        torch.testing.assert_close(gx, want, rtol=1e-4, atol=1e-4)
+        assert torch.isfinite(gx).all()

@@ -704,7 +704,7 @@ def test_ext_numpy_entry_points(ext, oracle_mod):
     width = int((full != 1600).sum(axis=1).max())
     assert isinstance(got, np.ndarray) and got.dtype == np.int64 and got.shape == (1600, width)
     assert np.array_equal(got, full[:, :width])
-    with pytest.raises(RuntimeError, match="512 or more"):
+    with pytest.raises(RuntimeError, match="more than 512"):
         ext.radius_neighbors(pts, pts, lengths, lengths, 5.0)
     # grid_subsampling
     sp, sl = ext.grid_subsampling(pts, lengths, 0.1)

@@ -861,9 +861,9 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lenghts, radius):
     """(total_q, max_count) int64 neighbour table, ascending by distance, padded with total_s
     (csrc/cpu/radius_neighbors/radius_neighbors.cpp:5-93; keyword `s_lenghts` as registered, pybind.cpp:41).
 
-    Differences: points AT the radius are included (the GPU path follows ops/radius_search.py:66, the CPU code's nanoflann
-    search is strict), and the table is at most 512 wide (the search kernel's list): a query with 512 or more neighbours
-    raises instead of widening it further."""
+    Strict like the CPU code's nanoflann search (supports exactly AT the radius are left out: the table of the
+    inclusive search kernel is cut at the strict count of every query).  Difference: the table is at most 512 wide (the
+    search kernel's list); a query with more than 512 neighbours raises instead of widening it further."""
     import numpy as np
 
     q, s = _np_to_dev(q_points, np.float32), _np_to_dev(s_points, np.float32)
@@ -871,19 +871,16 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lenghts, radius):
     if q.shape[0] == 0:
         return np.zeros((0, 0), dtype=np.int64)
     counts = torch.empty((q.shape[0],), dtype=torch.long, device=q.device)
-    radius_count_pack(q, s, ql, sl, counts, float(radius))
-    widest = int(counts.max().item())  # strict count; supports exactly AT the radius come on top of it
-    filled = limit = 0
-    for limit in (64, 128, 512):
-        if widest >= limit and limit < 512:
-            continue
-        out = torch.empty((q.shape[0], limit), dtype=torch.long, device=q.device)
-        radius_search_pack(q, s, ql, sl, out, float(radius), limit)
-        filled = int((out != s.shape[0]).sum(dim=1).max().item())
-        if filled < limit:
-            break
-    if filled >= limit:
-        raise RuntimeError("radius_neighbors: a query has 512 or more neighbours; use radius_search_pack_mode with a limit")
+    radius_count_pack(q, s, ql, sl, counts, float(radius))  # strict: radius - d > 0
+    filled = int(counts.max().item())
+    if filled > 512:
+        raise RuntimeError("radius_neighbors: a query has more than 512 neighbours; use radius_search_pack_mode with a limit")
+    limit = next(w for w in (64, 128, 256, 512) if filled <= w)
+    out = torch.empty((q.shape[0], limit), dtype=torch.long, device=q.device)
+    radius_search_pack(q, s, ql, sl, out, float(radius), limit)
+    # ascending by distance: what the inclusive search adds (d == radius) sits behind the strict neighbours
+    keep = torch.arange(limit, device=q.device).unsqueeze(0) < counts.unsqueeze(1)
+    out = torch.where(keep, out, torch.full_like(out, s.shape[0]))
     return out[:, :filled].cpu().numpy()
 
 

@@ -38,6 +38,10 @@ def _select(score_mat: Tensor, k: int, row_masks, col_masks, largest, threshold,
                            row_masks=row_masks, col_masks=col_masks, largest=largest, threshold=threshold,
                            mutual=mutual)
     n = int(count.item())  # the one sync torch.nonzero has too
+    if score_mat.requires_grad and torch.is_grad_enabled():
+        # the reference returns score_mat[rows, cols] (mutual_topk_select.py:57,:130), which autograd follows; the
+        # kernel's copy of the same values is detached, so gather them through torch when a gradient can be asked for
+        return idx[0, :n], idx[1, :n], idx[2, :n], score_mat[idx[0, :n], idx[1, :n], idx[2, :n]]
     return idx[0, :n], idx[1, :n], idx[2, :n], scores[:n].to(score_mat.dtype)
 
 

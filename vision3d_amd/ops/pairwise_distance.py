@@ -32,12 +32,18 @@ class _PairwiseDistanceFunction(Function):
             if not squared:
                 g = torch.where(out > 0, g / (2.0 * out), torch.zeros_like(g))
         else:
+            # clamp(min=0) (pairwise_distance.py:53) blocks the gradient where it clipped.  A clipped cell holds exactly
+            # 0, resp. exactly sqrt(0 + eps) in fp32 (correctly rounded in the kernel and in torch alike): the mask is
+            # a comparison with that one value, not a rounding-dependent out*out > eps.  Cells whose unclamped value
+            # is exactly 0 (or within eps rounding of it) are masked too, where torch's clamp lets the gradient pass:
+            # a set of measure zero, and for coinciding points the gradient 2 g (x - y) vanishes either way.
             if not squared:
+                floor = torch.sqrt(torch.tensor(eps, dtype=out.dtype, device=out.device))
                 g = g / (2.0 * out)  # out = sqrt(clamp(d) + eps) > 0
-                live = out * out > eps
+                live = out > floor
             else:
                 live = out > 0
-            g = torch.where(live, g, torch.zeros_like(g))  # clamp(min=0) blocks the gradient where it clipped
+            g = torch.where(live, g, torch.zeros_like(g))
         grad_x = grad_y = None
         if normalized and not strict:  # d = 2 - 2 x.y
             if ctx.needs_input_grad[0]:
