@@ -206,7 +206,7 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
 
 static int launch_pairwise(const float* x, const float* y, float* out, int batch, int N, int M, int C,
                            int64_t y_batch_stride, int64_t out_ld, int flags, float eps, hipStream_t stream) {
-  const bool fast = (C % PD_BK == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && N > 0 && M > 0;
+  const bool fast = C > 0 && (C % PD_BK == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && N > 0 && M > 0;
   const int vec_out = (M % 4 == 0) && (out_ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
   dim3 grid((unsigned)ceil_div(M, PD_BN), (unsigned)ceil_div(N, PD_BM), (unsigned)batch);
 #define V3D_LAUNCH_PD(S_, F_)                                                                                   \
