@@ -328,3 +328,18 @@ def test_pairwise_distance_backward_blocks_exactly_the_clipped_cells(ext):
         want = 2.0 * (gm.sum(-1, keepdim=True) * x - torch.matmul(gm, y))
         torch.testing.assert_close(gx, want, rtol=1e-4, atol=1e-4)
         assert torch.isfinite(gx).all()
+
+
+def test_pack_mode_ops_take_lengths_on_the_host_and_in_int32(ext):
+    """The reference reads lengths with `.item()` loops (ops/conversion.py:7-12): any device, any integer type."""
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    pts = torch.rand((700, 3), generator=g).to(DEV)
+    dev_len = torch.tensor([300, 400], device=DEV)
+    host_len = torch.tensor([300, 400], dtype=torch.int32)
+    assert torch.equal(ops.knn_pack_mode(pts, pts, host_len, host_len, 6), ops.knn_pack_mode(pts, pts, dev_len, dev_len, 6))
+    assert torch.equal(ops.radius_search_pack_mode(pts, pts, host_len, host_len, 0.1, 20),
+                       ops.radius_search_pack_mode(pts, pts, dev_len, dev_len, 0.1, 20))
+    assert torch.equal(ops.radius_count_pack_mode(pts, pts, host_len, host_len, 0.1),
+                       ops.radius_count_pack_mode(pts, pts, dev_len, dev_len, 0.1))

@@ -117,8 +117,9 @@ def knn_pack_mode(
         return padded_knn_pack_mode(q_points, s_points, q_lengths, s_lengths, k, return_distance, inf)
     distances = q_points.new_empty((q_points.shape[0], k))
     indices = torch.empty((q_points.shape[0], k), dtype=torch.long, device=q_points.device)
-    ext.knn_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.to(torch.long).contiguous(),
-                 s_lengths.to(torch.long).contiguous(), distances, indices, k)
+    dev = q_points.device  # the reference's loops take the lengths on either side and in any integer type
+    ext.knn_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.to(device=dev, dtype=torch.long).contiguous(),
+                 s_lengths.to(device=dev, dtype=torch.long).contiguous(), distances, indices, k)
     return (distances, indices) if return_distance else indices
 
 

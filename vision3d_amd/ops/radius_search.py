@@ -10,6 +10,12 @@ from .conversion import batch_to_pack, pack_to_batch
 from .knn import keops_knn
 
 
+def _device_lengths(lengths, like):
+    """The kernels read the lengths on the device as int64; the reference's loops accept them on either side and in any
+    integer type (`lengths[i].item()`, ops/conversion.py:7-12)."""
+    return lengths.to(device=like.device, dtype=torch.long).contiguous()
+
+
 def radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, inf=1e10):
     """q_points (M, 3), s_points (N, 3), lengths (B,) -> neighbor indices (M, neighbor_limit), N where absent.
 
@@ -19,8 +25,8 @@ def radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, ne
     if (q_points.dtype == torch.float32 and s_points.dtype == torch.float32 and q_points.shape[-1] == 3
             and 0 < neighbor_limit <= 512):
         out = torch.empty((q_points.shape[0], neighbor_limit), dtype=torch.long, device=q_points.device)
-        ext.radius_search_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.contiguous(),
-                               s_lengths.contiguous(), out, radius, neighbor_limit)
+        ext.radius_search_pack(q_points.contiguous(), s_points.contiguous(), _device_lengths(q_lengths, q_points),
+                               _device_lengths(s_lengths, q_points), out, radius, neighbor_limit)
         return out
     return padded_radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit, inf)
 
@@ -45,8 +51,8 @@ def radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf
     padded route.  ``inf`` is only used by that route."""
     if q_points.dtype == torch.float32 and s_points.dtype == torch.float32 and q_points.shape[-1] == 3:
         counts = torch.zeros((q_points.shape[0],), dtype=torch.long, device=q_points.device)
-        ext.radius_count_pack(q_points.contiguous(), s_points.contiguous(), q_lengths.contiguous(),
-                              s_lengths.contiguous(), counts, radius)
+        ext.radius_count_pack(q_points.contiguous(), s_points.contiguous(), _device_lengths(q_lengths, q_points),
+                              _device_lengths(s_lengths, q_points), counts, radius)
         return counts
     return padded_radius_count_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, inf)
 
