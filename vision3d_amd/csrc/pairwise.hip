@@ -444,13 +444,16 @@ __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __r
       if (lane == j) dist = sqrtf(tot);
     }
   }
-  // rank sort among the k entries (k <= 64): position = number of entries that precede mine
+  // rank sort among the k entries (k <= 64): position = number of entries that precede mine.  (distance, index) as one
+  // 64-bit key -- distances are sqrt results, >= +0, so the bit pattern orders like the value; unfilled entries carry the
+  // largest key -- makes "precedes" a single compare per entry.
+  const unsigned long long key =
+      idx < 0 ? ~0ull : (((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(unsigned)idx);
   int rank = 0;
   for (int j = 0; j < k; ++j) {
-    const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dist), j));
-    const int ij = __builtin_amdgcn_readlane(idx, j);
-    const bool before = (ij >= 0) && (idx < 0 || dj < dist || (dj == dist && ij < idx));
-    rank += before ? 1 : 0;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, j);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), j);
+    rank += ((((unsigned long long)hi) << 32) | lo) < key ? 1 : 0;
   }
   if (lane < k) {
     // unfilled entries (M < k) all tie: keep them behind the real ones in lane order
