@@ -231,6 +231,7 @@ __device__ __forceinline__ float wave_shr1(float v) {
 __device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 
 constexpr int kTopkCand = 192;  // candidates ranked in LDS per row
+constexpr int kTopkAhead = 8;   // 64-column groups requested together on the insertion path
 
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ D, int64_t rows, int ncols,
                                                         int64_t ld, int col_base, int k, int first_chunk,
@@ -275,10 +276,11 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
     // search, one compare + ballot + popcount per bit
     const unsigned lbits = __float_as_uint(lmin);
     unsigned prefix = 0;
-    for (int bit = 30; bit >= 0; --bit) {
+    for (int bit = 30; bit >= 7; --bit) {  // the low 7 bits are not searched: all ones keeps it an upper bound, 2^-17 looser
       const unsigned trial = prefix | (1u << bit);
       if (__builtin_popcountll(__ballot(lbits < trial)) <= k - 1) prefix = trial;
     }
+    prefix |= 0x7fu;
     const float kth = __uint_as_float(prefix);
     // strict '<' below must still admit values equal to the bound: step to the next float (kth >= 0)
     cap = kth < INFINITY ? __uint_as_float(__float_as_uint(kth) + 1u) : INFINITY;
@@ -305,7 +307,8 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
           const bool in = c + q < ncols && e[q] < cap;
           const unsigned long long m = __ballot(in);
           const int slot = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-          if (in && slot < kTopkCand) cand[slot] = make_float2(e[q], __int_as_float(col_base + c + q));
+          // (column, distance) so that the pair read as one 64-bit word orders by (distance, column); -0 becomes +0
+          if (in && slot < kTopkCand) cand[slot] = make_float2(__int_as_float(col_base + c + q), e[q] == 0.f ? 0.f : e[q]);
           count += __builtin_popcountll(m);
         }
       }
@@ -314,24 +317,34 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       for (int j0 = 0; j0 < count; j0 += 64) {
         const int j = j0 + lane;
-        const float2 me = cand[j < count ? j : 0];
+        const unsigned long long* cand64 = reinterpret_cast<const unsigned long long*>(cand);
+        const unsigned long long me = cand64[j < count ? j : 0];  // distances are >= +0: the bit pattern orders like the value
         int rank = 0;
-        for (int i = 0; i < count; ++i) {
-          const float2 o = cand[i];  // same address in every lane: LDS broadcast
-          rank += (o.x < me.x || (o.x == me.x && __float_as_int(o.y) < __float_as_int(me.y))) ? 1 : 0;
-        }
+        for (int i = 0; i < count; ++i) rank += cand64[i] < me ? 1 : 0;  // same address in every lane: LDS broadcast
         if (j < count && rank < k) {
-          run_d[row * k + rank] = me.x;
-          run_i[row * k + rank] = __float_as_int(me.y);
+          run_d[row * k + rank] = __uint_as_float((unsigned)(me >> 32));
+          run_i[row * k + rank] = (int)(unsigned)me;
         }
       }
       return;
     }
   }
   float tau = fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1)), cap);
-  for (int c0 = 0; c0 < ncols; c0 += 64) {
+  for (int c00 = 0; c00 < ncols; c00 += 64 * kTopkAhead) {
+    // kTopkAhead loads in flight per lane (the row is read once, front to back: one load per 64 columns and its wait
+    // would leave the pass latency-bound); the 64-column groups are then taken in ascending order, as the tie rule of
+    // the insertion needs
+    float dv[kTopkAhead];
+#pragma unroll
+    for (int u = 0; u < kTopkAhead; ++u) {
+      const int c = c00 + u * 64 + lane;
+      dv[u] = drow[c < ncols ? c : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < kTopkAhead; ++u) {
+    const int c0 = c00 + u * 64;
     const int c = c0 + lane;
-    const float d = c < ncols ? drow[c] : INFINITY;
+    const float d = c < ncols ? dv[u] : INFINITY;
     unsigned long long m = __ballot(d < tau);
     while (m) {
       const int l = __builtin_ffsll((long long)m) - 1;
@@ -351,6 +364,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       }
       tau = fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_), k - 1)), cap);
       m = __ballot(d < tau) & ~((2ull << l) - 1ull);
+    }
     }
   }
   if (lane < k) {
