@@ -8,13 +8,14 @@ import csv
 import sys
 from collections import defaultdict
 
-SHAPES = {  # grid threads of v3d::pairwise_distance_kernel<false, true> -> the launch it is
-    1048576: "pairwise_distance B1 N8192 M8192 C256 (opbench)",
-    4194304: "pairwise_distance B1 N16384 M16384 C64 (opbench)",
-    524288: "pairwise_distance B32 N1024 M1024 C64 (BASELINE config 3; also inside knn_feat k20)",
-    400384: "knn_feat B1 N12500 M100000 C256 k3: distance chunk 12500 x 16000",
-    501760: "knn_feat B1 N100000 M12500 C256 k1 (config 5, one-GPU shard): distance chunk 100000 x 2432..2560",
-    50176: "knn_feat B1 N12500 M100000: last chunk",
+SHAPES = {  # grid threads of v3d::pairwise_distance_kernel<false, true> (256 per 128 x 128 tile) -> the launch it is
+    1048576: "pairwise_distance B1 N8192 M8192 C256 (opbench): 64 x 64 tiles",
+    4194304: "pairwise_distance B1 N16384 M16384 C64 (opbench): 128 x 128 tiles",
+    524288: "pairwise_distance B32 N1024 M1024 C64 (BASELINE config 3; also inside knn_feat k20): 32 x 8 x 8 tiles",
+    1601536: "knn_feat B1 N100000 M12500 C256 k1 (config 5, one-GPU shard): chunk 100000 x 1024 = 782 x 8 tiles",
+    400384: "same call, last chunk 100000 x 212: 782 x 2 tiles",
+    501760: "knn_feat B1 N12500 M100000 C256 k3: chunk 12500 x 2560 = 98 x 20 tiles",
+    50176: "same call, last chunk 12500 x 160: 98 x 2 tiles",
 }
 
 
