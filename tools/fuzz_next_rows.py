@@ -23,7 +23,75 @@ def table(rng, m, k, n):
 
 
 def one_case(rng, i):
-    kind = i % 12
+    kind = i % 16
+    if kind == 12:  # backward scatters (scatter.hip): every channel-tile / chunk geometry, both dtypes, skewed indices
+        dt = np.float32 if rng.integers(4) else np.float64
+        b, c = int(rng.integers(1, 4)), int(rng.integers(1, 40))
+        n = int(rng.choice([1, 7, 300, 1024, 1025, 4096, 4100]))
+        if rng.integers(2):  # group gather
+            m, k = int(rng.integers(1, 700)), int(rng.integers(1, 40))
+            idx = rng.integers(0, n, size=(b, m, k)).astype(np.int64)
+            if rng.integers(3) == 0:
+                idx[:] = idx % max(1, n // 50)  # few sources collect everything
+            g = rng.standard_normal((b, c, m, k)).astype(dt)
+            want = oracle.group_gather_backward(g, idx, n)
+            got = torch.empty((b, c, n), dtype=T(g).dtype, device=DEV)
+            ext.group_gather_backward(T(g), T(idx), got, n)
+            return np.array_equal(N_(got), want), f"group_gather_bwd {dt.__name__} b{b} c{c} n{n} m{m} k{k}"
+        q = int(rng.integers(1, 6000))
+        idx = rng.integers(0, n, size=(b, q, 3)).astype(np.int64)
+        w = rng.random((b, q, 3)).astype(dt)
+        g = rng.standard_normal((b, c, q)).astype(dt)
+        want = oracle.three_interpolate_backward(g, idx, w, n)
+        got = torch.empty((b, c, n), dtype=T(g).dtype, device=DEV)
+        ext.three_interpolate_backward(T(g), T(idx), T(w), got, n)
+        return np.array_equal(N_(got), want), f"three_interp_bwd {dt.__name__} b{b} c{c} n{n} q{q}"
+    if kind == 13:  # pack-mode kNN on the packed arrays against the knn_points oracle per cloud
+        b = int(rng.integers(1, 7))
+        k = int(rng.choice([1, 2, 5, 16, 23, 24, 40, 63, 64, 100]))
+        sl = rng.integers(0, 1500, size=b).astype(np.int64)
+        ql = rng.integers(0, 300, size=b).astype(np.int64)
+        s = rng.random((int(sl.sum()), 3), dtype=np.float32)
+        if rng.integers(3) == 0:
+            s = (np.round(s * 6) / 6).astype(np.float32)  # lattice: ties
+        qq = rng.random((int(ql.sum()), 3), dtype=np.float32)
+        d = torch.full((qq.shape[0], k), -1.0, device=DEV)
+        i_ = torch.full((qq.shape[0], k), -7, dtype=torch.long, device=DEV)
+        ext.knn_pack(T(qq), T(s), T(ql), T(sl), d, i_, k)
+        ok, qo, so = True, 0, 0
+        for a, c in zip(ql, sl):
+            if a:
+                wd, wi = oracle.knn_points(qq[None, qo:qo + a], s[None, so:so + c], k)
+                ok = ok and np.array_equal(N_(i_)[qo:qo + a], wi[0]) and np.array_equal(N_(d)[qo:qo + a], wd[0])
+            qo, so = qo + a, so + c
+        return ok, f"knn_pack b{b} k{k} ql{ql.tolist()} sl{sl.tolist()}"
+    if kind == 14:  # radius search with the wide lists (limits 129 .. 512)
+        b = int(rng.integers(1, 4))
+        sl = rng.integers(0, 2500, size=b).astype(np.int64)
+        ql = rng.integers(0, 200, size=b).astype(np.int64)
+        s = rng.random((int(sl.sum()), 3), dtype=np.float32)
+        if rng.integers(3) == 0:
+            s = (np.round(s * 8) / 8).astype(np.float32)
+        qq = rng.random((int(ql.sum()), 3), dtype=np.float32)
+        limit, r = int(rng.integers(129, 513)), float(rng.choice([0.125, 0.2, 0.35, 0.6]))
+        want = oracle.radius_search_pack(qq, s, ql, sl, r, limit)
+        got = torch.full((qq.shape[0], limit), -7, dtype=torch.long, device=DEV)
+        ext.radius_search_pack(T(qq), T(s), T(ql), T(sl), got, r, limit)
+        return np.array_equal(N_(got), want), f"radius_search b{b} limit{limit} r{r} ql{ql.tolist()} sl{sl.tolist()}"
+    if kind == 15:  # feature kNN on both routes (wave per row up to k = 64, workgroup per row above)
+        b, n, m = int(rng.integers(1, 3)), int(rng.integers(1, 200)), int(rng.integers(1, 1500))
+        c, k = int(rng.choice([3, 8, 32, 64, 96])), int(rng.choice([1, 7, 20, 52, 64, 65, 100, 300]))
+        x = rng.standard_normal((b, n, c)).astype(np.float32)
+        y = rng.standard_normal((b, m, c)).astype(np.float32)
+        wd, wi = oracle.knn_feat(x, y, k)
+        d = torch.empty((b, n, k), device=DEV)
+        i_ = torch.empty((b, n, k), dtype=torch.long, device=DEV)
+        ext.knn_feat(T(x), T(y), d, i_, k)
+        kk = min(k, m)
+        gd, gi = N_(d), N_(i_)
+        ok = np.all(gi[..., kk:] == -1) and np.all(np.abs(gd[..., :kk] - wd[..., :kk]) <= 1e-4 * (1 + wd[..., :kk]))
+        ok = ok and (gi[..., :kk] != wi[..., :kk]).mean() < 5e-3 and np.all(np.diff(gd[..., :kk], axis=-1) >= 0)
+        return bool(ok), f"knn_feat b{b} n{n} m{m} c{c} k{k}"
     if kind == 6:  # threshold selection and global top-k on one matrix (ties on purpose: quantised scores)
         n, m = int(rng.integers(1, 1300)), int(rng.integers(1, 1300))
         score = np.round(rng.standard_normal((n, m)) * rng.choice([1, 4, 50, 1000])).astype(np.float32) / 4
