@@ -18,42 +18,61 @@ namespace v3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PD_BM = 128, PD_BN = 128, PD_BK = 32, PD_THREADS = 256;
-constexpr int PD_LD = PD_BM;              // k-major LDS tiles [k][row ^ swizzle(k)], 128 floats per k
-constexpr int PD_TILE = PD_BK * PD_LD;    // floats per operand tile (16 KiB)
+constexpr int PD_LD = PD_BM + 1;          // k-major LDS tiles [k][row], 129 floats per k (see pd_addr)
+constexpr int PD_TILE = PD_BK * PD_LD;    // floats per operand tile (16.1 KiB)
+static_assert(2 * PD_TILE >= 64 * PD_BN, "the operand tiles double as the 64 x 128 output staging area");
 
 // A (128 rows x 32 k) slab of a row-major (rows x C) matrix, 4 float4 per thread.  Held in registers between the
 // global load (issued before the MFMA loop of the previous slab) and the transposing LDS store (after it).
 struct PdSlab {
   float4 v[4];
 };
-// FAST (C % 32 == 0, 16-byte aligned rows): unconditional float4 loads -- rows past the end are clamped to the last
-// row (their results are never stored) so that no load sits behind a branch: hipcc otherwise branches around every
-// guarded load and drains the memory pipe per element.  The generic form handles any C / alignment.
-template <bool FAST>
+// Generic slab load: any C / alignment / edge, one guarded scalar load per element.
 __device__ __forceinline__ void pd_load(PdSlab& s, const float* __restrict__ base, int rows, int C, int row0, int k0) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int f = it * PD_THREADS + threadIdx.x;
     const int r = f >> 3, k4 = (f & 7) * 4;
     const int row = row0 + r, k = k0 + k4;
-    if (FAST) {
-      s.v[it] = *reinterpret_cast<const float4*>(base + (int64_t)min(row, rows - 1) * C + k);
-    } else {
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < rows) {
-        const float* p = base + (int64_t)row * C + k;
-        if (k + 0 < C) t.x = p[0];
-        if (k + 1 < C) t.y = p[1];
-        if (k + 2 < C) t.z = p[2];
-        if (k + 3 < C) t.w = p[3];
-      }
-      s.v[it] = t;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows) {
+      const float* p = base + (int64_t)row * C + k;
+      if (k + 0 < C) t.x = p[0];
+      if (k + 1 < C) t.y = p[1];
+      if (k + 2 < C) t.z = p[2];
+      if (k + 3 < C) t.w = p[3];
     }
+    s.v[it] = t;
   }
 }
-// LDS element (k, r) lives at k*128 + (r ^ (k & ~3)): fragment reads (fixed k, 32 consecutive r) stay conflict-free
-// and the transposing stores of one wave (8 rows x 8 k-groups) spread over all 32 banks (2-way instead of 4-way).
-__device__ __forceinline__ int pd_addr(int k, int r) { return k * PD_LD + (r ^ (k & 28)); }
+// FAST slab load (C % 32 == 0, 16-byte aligned rows, at least 128 rows so that every tile is a whole one -- the last
+// tile of a dimension is moved back to end at the matrix edge and recomputes a few rows of its neighbour): four
+// buffer_load_dwordx4 whose address is a tile descriptor (scalar registers) + ONE per-thread byte offset + a scalar
+// offset carrying the row group and k0.  Nothing per-load lives in vector registers: eight 64-bit pointers (or their
+// spills) were what kept the k loop above 128 registers.
+typedef unsigned pd_u32x4 __attribute__((ext_vector_type(4)));
+struct PdTileSrc {
+  __amdgpu_buffer_rsrc_t rsrc;  // the tile's 128 rows: base + row0 * C, 128 * C * 4 bytes
+  unsigned voff;                // this thread's (row tid/8, k group tid%8) inside it, bytes
+};
+__device__ __forceinline__ PdTileSrc pd_tile_src(const float* __restrict__ base, int C, int row0) {
+  PdTileSrc t;
+  t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)row0 * C), 0, PD_BM * C * 4, 0x00020000);
+  t.voff = ((threadIdx.x >> 3) * (unsigned)C + (threadIdx.x & 7) * 4) * 4u;
+  return t;
+}
+__device__ __forceinline__ void pd_load_fast(PdSlab& s, const PdTileSrc& src, int C, int k0) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const pd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, src.voff, (it * 32 * C + k0) * 4, 0);
+    s.v[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
+}
+// LDS element (k, r) lives at k*129 + r.  Fragment reads (fixed k, 32 consecutive r) are conflict-free under any pitch;
+// the odd pitch spreads the transposing stores of a half-wave (4 rows x 8 k-groups, bank = (k + r) mod 32) over all 32
+// banks, and -- unlike an XOR swizzle -- leaves every address of the k loop at a compile-time distance from one base
+// register per operand (an XOR swizzle cost ~30 address registers, i.e. a workgroup per CU).
+__device__ __forceinline__ int pd_addr(int k, int r) { return k * PD_LD + r; }
 __device__ __forceinline__ void pd_store(const PdSlab& s, float* lds) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -72,18 +91,20 @@ __device__ __forceinline__ void pd_store(const PdSlab& s, float* lds) {
 // the current slab; the transposing LDS stores follow between two barriers.  Epilogue: distances go through LDS
 // (reusing the operand tiles) so every lane stores 16 contiguous bytes and a wave 512-byte row segments.
 template <bool STRICT, bool FAST>
-__global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const float* __restrict__ x,
-                                                                       const float* __restrict__ y,
-                                                                       float* __restrict__ out, int N, int M, int C,
-                                                                       int64_t y_batch_stride, int64_t out_ld,
-                                                                       int flags, float eps, int vec_out) {
+__device__ __forceinline__ void pairwise_distance_tile(const float* __restrict__ x, const float* __restrict__ y,
+                                                       float* __restrict__ out, int N, int M, int C,
+                                                       int64_t y_batch_stride, int64_t out_ld, int flags, float eps,
+                                                       int vec_out) {
   __shared__ __align__(16) float smem[2 * PD_TILE];  // xs | ys, later the 64 x 128 output staging area
   __shared__ float x2s[PD_BM];
   __shared__ float y2s[PD_BN];
   float* xs = smem;
   float* ys = smem + PD_TILE;
   const int b = blockIdx.z;
-  const int row0 = blockIdx.y * PD_BM, col0 = blockIdx.x * PD_BN;
+  // FAST: N, M >= 128 and the last tile of each dimension ends at the edge (overlapping its neighbour, which computes
+  // the same values for the shared cells), so no tile has rows or columns to mask
+  const int row0 = FAST ? min((int)blockIdx.y * PD_BM, N - PD_BM) : blockIdx.y * PD_BM;
+  const int col0 = FAST ? min((int)blockIdx.x * PD_BN, M - PD_BN) : blockIdx.x * PD_BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
   const float* xb = x + (int64_t)b * N * C;
@@ -100,16 +121,29 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
 
   const int l31 = lane & 31, lh = lane >> 5;
   PdSlab sx, sy;
-  pd_load<FAST>(sx, xb, N, C, row0, 0);
-  pd_load<FAST>(sy, yb, M, C, col0, 0);
+  PdTileSrc tx, ty;
+  if (FAST) {
+    tx = pd_tile_src(xb, C, row0);
+    ty = pd_tile_src(yb, C, col0);
+    pd_load_fast(sx, tx, C, 0);
+    pd_load_fast(sy, ty, C, 0);
+  } else {
+    pd_load(sx, xb, N, C, row0, 0);
+    pd_load(sy, yb, M, C, col0, 0);
+  }
   for (int k0 = 0; k0 < C; k0 += PD_BK) {
     __syncthreads();  // every wave is done reading the previous slab
     pd_store(sx, xs);
     pd_store(sy, ys);
     __syncthreads();
     if (k0 + PD_BK < C) {  // next slab: in flight while this one is multiplied
-      pd_load<FAST>(sx, xb, N, C, row0, k0 + PD_BK);
-      pd_load<FAST>(sy, yb, M, C, col0, k0 + PD_BK);
+      if (FAST) {
+        pd_load_fast(sx, tx, C, k0 + PD_BK);
+        pd_load_fast(sy, ty, C, k0 + PD_BK);
+      } else {
+        pd_load(sx, xb, N, C, row0, k0 + PD_BK);
+        pd_load(sy, yb, M, C, col0, k0 + PD_BK);
+      }
     }
     if (STRICT) {
       for (int k = 0; k < PD_BK; ++k) {
@@ -129,27 +163,38 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
       }
       continue;
     }
-    {
-      const float* t = tid < 128 ? xs : ys;
-      const int r = tid & 127;
+    // operand fragments of step kk+2 are requested before the four MFMAs of step kk are issued, so the LDS latency
+    // runs under 256 cycles of matrix work instead of in front of it
+    // (the two values per step of this thread's norm row travel with them; the FMA chain stays in k order)
+    const float* nt = tid < 128 ? xs : ys;
+    const int nr = tid & 127;
+    float a[2][2], bb[2][2], nv[2][2];
 #pragma unroll
-      for (int k = 0; k < PD_BK; ++k) {
-        const float v = t[pd_addr(k, r)];
-        norm = __builtin_fmaf(v, v, norm);
-      }
-    }
+    for (int i = 0; i < 2; ++i) a[0][i] = xs[pd_addr(lh, wr * 64 + i * 32 + l31)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bb[0][j] = ys[pd_addr(lh, wc * 64 + j * 32 + l31)];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) nv[0][u] = nt[pd_addr(u, nr)];
 #pragma unroll
     for (int kk = 0; kk < PD_BK; kk += 2) {
-      float a[2], bb[2];
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < PD_BK) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = xs[pd_addr(kk + lh, wr * 64 + i * 32 + l31)];
+        for (int i = 0; i < 2; ++i) a[nxt][i] = xs[pd_addr(kk + 2 + lh, wr * 64 + i * 32 + l31)];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bb[j] = ys[pd_addr(kk + lh, wc * 64 + j * 32 + l31)];
+        for (int j = 0; j < 2; ++j) bb[nxt][j] = ys[pd_addr(kk + 2 + lh, wc * 64 + j * 32 + l31)];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) nv[nxt][u] = nt[pd_addr(kk + 2 + u, nr)];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the reads back below the MFMAs they should overlap
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+      norm = __builtin_fmaf(nv[cur][0], nv[cur][0], norm);
+      norm = __builtin_fmaf(nv[cur][1], nv[cur][1], norm);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (tid < 128) x2s[tid] = norm; else y2s[tid - 128] = norm;
@@ -204,18 +249,39 @@ __global__ __launch_bounds__(PD_THREADS) void pairwise_distance_kernel(const flo
   }
 }
 
+// Occupancy is what the MFMA form is built around: a workgroup in its store / barrier phases or in its epilogue leaves
+// the matrix pipe to the others on its CU.  Left to itself hipcc takes 184-208 registers (two workgroups per CU); the
+// fast form fits 128 (64 of them accumulators) = four workgroups, the generic form 168 = three.  Measured: three
+// instead of two, C=64 shapes 9-16 % faster and C=256 5-8 %.  The strict (VALU) form needs its 230 registers.
+__global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void pairwise_distance_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int M, int C,
+    int64_t y_batch_stride, int64_t out_ld, int flags, float eps, int vec_out) {
+  pairwise_distance_tile<false, true>(x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, vec_out);
+}
+__global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void pairwise_distance_generic_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int M, int C,
+    int64_t y_batch_stride, int64_t out_ld, int flags, float eps, int vec_out) {
+  pairwise_distance_tile<false, false>(x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, vec_out);
+}
+template <bool FAST>
+__global__ __launch_bounds__(PD_THREADS) void pairwise_distance_strict_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int M, int C,
+    int64_t y_batch_stride, int64_t out_ld, int flags, float eps, int vec_out) {
+  pairwise_distance_tile<true, FAST>(x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, vec_out);
+}
+
 static int launch_pairwise(const float* x, const float* y, float* out, int batch, int N, int M, int C,
                            int64_t y_batch_stride, int64_t out_ld, int flags, float eps, hipStream_t stream) {
-  const bool fast = C > 0 && (C % PD_BK == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && N > 0 && M > 0;
+  const bool fast = C > 0 && C <= (1 << 20) && (C % PD_BK == 0) && N >= PD_BM && M >= PD_BN && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && N > 0 && M > 0;
   const int vec_out = (M % 4 == 0) && (out_ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
   dim3 grid((unsigned)ceil_div(M, PD_BN), (unsigned)ceil_div(N, PD_BM), (unsigned)batch);
-#define V3D_LAUNCH_PD(S_, F_)                                                                                   \
-  hipLaunchKernelGGL((pairwise_distance_kernel<S_, F_>), grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C, \
-                     y_batch_stride, out_ld, flags, eps, vec_out)
+#define V3D_LAUNCH_PD(K_)                                                                                         \
+  hipLaunchKernelGGL(K_, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, \
+                     vec_out)
   if (flags & V3D_PD_STRICT) {
-    if (fast) V3D_LAUNCH_PD(true, true); else V3D_LAUNCH_PD(true, false);
+    if (fast) V3D_LAUNCH_PD(pairwise_distance_strict_kernel<true>); else V3D_LAUNCH_PD(pairwise_distance_strict_kernel<false>);
   } else {
-    if (fast) V3D_LAUNCH_PD(false, true); else V3D_LAUNCH_PD(false, false);
+    if (fast) V3D_LAUNCH_PD(pairwise_distance_kernel); else V3D_LAUNCH_PD(pairwise_distance_generic_kernel);
   }
 #undef V3D_LAUNCH_PD
   return launch_status("pairwise_distance");
