@@ -85,6 +85,44 @@ __device__ __forceinline__ void pd_store(const PdSlab& s, float* lds) {
   }
 }
 
+// One 32-deep slab of the MFMA form: 16 steps of four v_mfma_f32_32x32x2_f32 (2x2 tiles of 32x32 per wave).  The
+// operand fragments of step kk+2 are requested before the four MFMAs of step kk are issued, so the LDS latency runs
+// under 256 cycles of matrix work instead of in front of it; the two values per step of this thread's norm row travel
+// with them (the norm's FMA chain stays in k order).
+__device__ __forceinline__ void pd_mfma_slab(const float* xs, const float* ys, f32x16 (&acc)[2][2], float& norm, int tid,
+                                             int wr, int wc, int l31, int lh) {
+  const float* nt = tid < 128 ? xs : ys;
+  const int nr = tid & 127;
+  float a[2][2], bb[2][2], nv[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a[0][i] = xs[pd_addr(lh, wr * 64 + i * 32 + l31)];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bb[0][j] = ys[pd_addr(lh, wc * 64 + j * 32 + l31)];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) nv[0][u] = nt[pd_addr(u, nr)];
+#pragma unroll
+  for (int kk = 0; kk < PD_BK; kk += 2) {
+    const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+    if (kk + 2 < PD_BK) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[nxt][i] = xs[pd_addr(kk + 2 + lh, wr * 64 + i * 32 + l31)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[nxt][j] = ys[pd_addr(kk + 2 + lh, wc * 64 + j * 32 + l31)];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) nv[nxt][u] = nt[pd_addr(kk + 2 + u, nr)];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the reads back below the MFMAs they should overlap
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+    norm = __builtin_fmaf(nv[cur][0], nv[cur][0], norm);
+    norm = __builtin_fmaf(nv[cur][1], nv[cur][1], norm);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // STRICT: the exact difference form sum_c (x_c - y_c)^2 (pairwise_distance.py:28-37) on the VALU, accumulated in
 // the same per-lane output layout as the MFMA path so both share staging and epilogue.
 // Pipeline per 32-deep k-slab: the next slab's global loads are issued first and stay in flight under the 64 MFMAs of
@@ -163,39 +201,7 @@ __device__ __forceinline__ void pairwise_distance_tile(const float* __restrict__
       }
       continue;
     }
-    // operand fragments of step kk+2 are requested before the four MFMAs of step kk are issued, so the LDS latency
-    // runs under 256 cycles of matrix work instead of in front of it
-    // (the two values per step of this thread's norm row travel with them; the FMA chain stays in k order)
-    const float* nt = tid < 128 ? xs : ys;
-    const int nr = tid & 127;
-    float a[2][2], bb[2][2], nv[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[0][i] = xs[pd_addr(lh, wr * 64 + i * 32 + l31)];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bb[0][j] = ys[pd_addr(lh, wc * 64 + j * 32 + l31)];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) nv[0][u] = nt[pd_addr(u, nr)];
-#pragma unroll
-    for (int kk = 0; kk < PD_BK; kk += 2) {
-      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-      if (kk + 2 < PD_BK) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[nxt][i] = xs[pd_addr(kk + 2 + lh, wr * 64 + i * 32 + l31)];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bb[nxt][j] = ys[pd_addr(kk + 2 + lh, wc * 64 + j * 32 + l31)];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) nv[nxt][u] = nt[pd_addr(kk + 2 + u, nr)];
-      }
-      __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the reads back below the MFMAs they should overlap
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
-      norm = __builtin_fmaf(nv[cur][0], nv[cur][0], norm);
-      norm = __builtin_fmaf(nv[cur][1], nv[cur][1], norm);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    pd_mfma_slab(xs, ys, acc, norm, tid, wr, wc, l31, lh);
   }
   if (tid < 128) x2s[tid] = norm; else y2s[tid - 128] = norm;
   __syncthreads();  // norms visible; operand tiles free for the output staging
@@ -258,6 +264,116 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     int64_t y_batch_stride, int64_t out_ld, int flags, float eps, int vec_out) {
   pairwise_distance_tile<false, true>(x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, vec_out);
 }
+// The MFMA form for whole tiles and vector stores, as a sweep: at most four workgroups per CU, each taking tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...  What the one-tile-per-workgroup form cannot do: (1) the first slab of the
+// next tile is requested during the last slab of this one, so no tile starts by waiting for memory; (2) the epilogue's
+// global stores are only ISSUED -- the workgroup goes on with the next tile while they drain (its next wait is for
+// loads issued before them), instead of ending and holding its CU slot until the last store is acknowledged.  With
+// one tile per workgroup the workgroups of a CU run in lock-step (they start together and take equally long), so
+// their k loops and their epilogues did not overlap: total time was the SUM of the k-loop time and the store time.
+constexpr int PD_SWEEP_WGS = 4 * 256;  // MI355X: 256 CUs x four workgroups (128 registers, 34 KB of LDS each)
+struct PdTileAt {
+  int b, row0, col0;
+};
+__device__ __forceinline__ PdTileAt pd_tile_at(int t, int tiles_x, int tiles_y, int N, int M) {
+  PdTileAt a;
+  const int per_b = tiles_x * tiles_y;
+  a.b = t / per_b;
+  const int rem = t - a.b * per_b;
+  const int ty = rem / tiles_x;
+  a.row0 = min(ty * PD_BM, N - PD_BM);  // the last tile of a dimension ends at the edge
+  a.col0 = min((rem - ty * tiles_x) * PD_BN, M - PD_BN);
+  return a;
+}
+template <bool SQRT>
+__global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void pairwise_distance_sweep_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int M, int C,
+    int64_t y_batch_stride, int64_t out_ld, int flags, float eps, int tiles_x, int tiles_y, int total) {
+  __shared__ __align__(16) float smem[2 * PD_TILE];  // xs | ys, later the 64 x 128 output staging area
+  __shared__ float x2s[PD_BM];
+  __shared__ float y2s[PD_BN];
+  float* xs = smem;
+  float* ys = smem + PD_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool normalized = flags & V3D_PD_NORMALIZED;
+  // every LDS address of the epilogue is one of these bases plus a compile-time offset (written as (row, column) index
+  // arithmetic hipcc builds -- and keeps across the k loop -- a register per staged row)
+  float* const stage = smem + (wr * 32 + 4 * lh) * PD_BN + wc * 64 + l31;
+  const float* const x2p = x2s + wr * 64 + 4 * lh;
+  const float* const y2p = y2s + wc * 64 + l31;
+
+  int t = blockIdx.x;  // < total: the grid is min(total, PD_SWEEP_WGS)
+  PdTileAt at = pd_tile_at(t, tiles_x, tiles_y, N, M);
+  PdTileSrc tx = pd_tile_src(x + (int64_t)at.b * N * C, C, at.row0);
+  PdTileSrc ty = pd_tile_src(y + (int64_t)at.b * y_batch_stride, C, at.col0);
+  PdSlab sx, sy;
+  pd_load_fast(sx, tx, C, 0);
+  pd_load_fast(sy, ty, C, 0);
+  for (;;) {
+    const PdTileAt cur = at;
+    const int t_next = t + (int)gridDim.x;
+    const bool more = t_next < total;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float norm = 0.f;  // threads 0..127: x row `tid`; 128..255: y row `tid-128`
+    for (int k0 = 0; k0 < C; k0 += PD_BK) {
+      __syncthreads();  // every wave is done reading the previous slab (or the previous tile's staged output)
+      pd_store(sx, xs);
+      pd_store(sy, ys);
+      __syncthreads();
+      if (k0 + PD_BK < C) {  // next slab: in flight while this one is multiplied
+        pd_load_fast(sx, tx, C, k0 + PD_BK);
+        pd_load_fast(sy, ty, C, k0 + PD_BK);
+      } else if (more) {  // first slab of the next tile: in flight under this tile's last slab and its epilogue
+        at = pd_tile_at(t_next, tiles_x, tiles_y, N, M);
+        tx = pd_tile_src(x + (int64_t)at.b * N * C, C, at.row0);
+        ty = pd_tile_src(y + (int64_t)at.b * y_batch_stride, C, at.col0);
+        pd_load_fast(sx, tx, C, 0);
+        pd_load_fast(sy, ty, C, 0);
+      }
+      pd_mfma_slab(xs, ys, acc, norm, tid, wr, wc, l31, lh);
+    }
+    // normalized inputs: d = 2 - 2 x.y (pairwise_distance.py:47) = (2 - 2 x.y) + 0, the general form (:51) on norms 2, 0
+    if (tid < 128) x2s[tid] = normalized ? 2.0f : norm; else y2s[tid - 128] = normalized ? 0.0f : norm;
+    __syncthreads();  // norms visible; operand tiles free for the output staging
+
+    float* ob = out + ((int64_t)cur.b * N + cur.row0) * out_ld + cur.col0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float y2 = y2p[j * 32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);  // + 4 * lh (in the bases) = row inside the 32 x 32 MFMA tile
+          float d = (x2p[i * 32 + rr] - 2.0f * acc[i][j][r]) + y2;  // :51
+          d = fmaxf(d, 0.0f);                                       // :53
+          if (SQRT) d = sqrtf(d + eps);                             // :56
+          stage[rr * PD_BN + j * 32] = d;  // staging row = 32*wr + (row in the MFMA tile) for this i
+        }
+      }
+      __syncthreads();
+      // 64 staged rows x 128 columns: 8 float4 per thread, a wave-instruction stores two 512-byte row segments
+      float* p = ob + (int64_t)(i * 32 + (tid >> 5)) * out_ld + (tid & 31) * 4;
+      const float* sp = smem + (tid >> 5) * PD_BN + (tid & 31) * 4;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {  // staged row it*8 + tid/32 = tile row (it/4)*64 + i*32 + (it%4)*8 + tid/32
+        const float4 v = *reinterpret_cast<const float4*>(sp + it * 8 * PD_BN);
+        *reinterpret_cast<float4*>(p + (int64_t)((it >> 2) * 64 + (it & 3) * 8) * out_ld) = v;
+      }
+      if (i == 0) __syncthreads();  // after i = 1 the next tile's first barrier stands between these reads and new writes
+    }
+    if (!more) break;
+    t = t_next;
+  }
+}
 __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void pairwise_distance_generic_kernel(
     const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int M, int C,
     int64_t y_batch_stride, int64_t out_ld, int flags, float eps, int vec_out) {
@@ -278,6 +394,19 @@ static int launch_pairwise(const float* x, const float* y, float* out, int batch
 #define V3D_LAUNCH_PD(K_)                                                                                         \
   hipLaunchKernelGGL(K_, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, \
                      vec_out)
+  if (fast && vec_out && !(flags & V3D_PD_STRICT)) {
+    const int64_t tiles_x = ceil_div(M, PD_BN), tiles_y = ceil_div(N, PD_BM), total = tiles_x * tiles_y * batch;
+    if (total <= (int64_t)INT32_MAX) {
+      const dim3 sweep((unsigned)std::min<int64_t>(total, PD_SWEEP_WGS));
+      if (flags & V3D_PD_SQRT)
+        hipLaunchKernelGGL(pairwise_distance_sweep_kernel<true>, sweep, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C,
+                           y_batch_stride, out_ld, flags, eps, (int)tiles_x, (int)tiles_y, (int)total);
+      else
+        hipLaunchKernelGGL(pairwise_distance_sweep_kernel<false>, sweep, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C,
+                           y_batch_stride, out_ld, flags, eps, (int)tiles_x, (int)tiles_y, (int)total);
+      return launch_status("pairwise_distance");
+    }
+  }
   if (flags & V3D_PD_STRICT) {
     if (fast) V3D_LAUNCH_PD(pairwise_distance_strict_kernel<true>); else V3D_LAUNCH_PD(pairwise_distance_strict_kernel<false>);
   } else {
