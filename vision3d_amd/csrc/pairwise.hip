@@ -290,7 +290,7 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int M, int C,
     int64_t y_batch_stride, int64_t out_ld, int flags, float eps, int tiles_x, int tiles_y, int total) {
   __shared__ __align__(16) float smem[2 * PD_TILE];  // xs | ys, later the 64 x 128 output staging area
-  __shared__ float x2s[PD_BM];
+  __shared__ __align__(16) float x2s[PD_BM];
   __shared__ float y2s[PD_BN];
   float* xs = smem;
   float* ys = smem + PD_TILE;
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   float* const stage = smem + (wr * 32 + 4 * lh) * PD_BN + wc * 64 + l31;
   const float* const x2p = x2s + wr * 64 + 4 * lh;
   const float* const y2p = y2s + wc * 64 + l31;
+  const unsigned ovoff = ((tid >> 5) * (unsigned)out_ld + (tid & 31) * 4) * 4u;  // this thread's cell of an 8-row group
 
   int t = blockIdx.x;  // < total: the grid is min(total, PD_SWEEP_WGS)
   PdTileAt at = pd_tile_at(t, tiles_x, tiles_y, N, M);
@@ -344,29 +345,37 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     if (tid < 128) x2s[tid] = normalized ? 2.0f : norm; else y2s[tid - 128] = normalized ? 0.0f : norm;
     __syncthreads();  // norms visible; operand tiles free for the output staging
 
-    float* ob = out + ((int64_t)cur.b * N + cur.row0) * out_ld + cur.col0;
+    // the tile's 128 output rows as a buffer: 128 * out_ld * 4 bytes < 2^32 (out_ld < 2^23 on this path)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        out + ((int64_t)cur.b * N + cur.row0) * out_ld + cur.col0, 0, (PD_BM - 1) * (int)out_ld * 4 + PD_BN * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      const float y2v[2] = {y2p[0], y2p[32]};
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float y2 = y2p[j * 32];
+      for (int q = 0; q < 4; ++q) {  // accumulator registers 4q..4q+3 = rows 8q + 4 lh + 0..3 of the MFMA tile
+        const float4 x2v = *reinterpret_cast<const float4*>(x2p + i * 32 + 8 * q);
+        const float x2[4] = {x2v.x, x2v.y, x2v.z, x2v.w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2);  // + 4 * lh (in the bases) = row inside the 32 x 32 MFMA tile
-          float d = (x2p[i * 32 + rr] - 2.0f * acc[i][j][r]) + y2;  // :51
-          d = fmaxf(d, 0.0f);                                       // :53
-          if (SQRT) d = sqrtf(d + eps);                             // :56
-          stage[rr * PD_BN + j * 32] = d;  // staging row = 32*wr + (row in the MFMA tile) for this i
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float d = (x2[u] - 2.0f * acc[i][j][4 * q + u]) + y2v[j];  // :51
+            d = fmaxf(d, 0.0f);                                        // :53
+            if (SQRT) d = sqrtf(d + eps);                              // :56
+            stage[(8 * q + u) * PD_BN + j * 32] = d;  // staging row = 32*wr + (row in the MFMA tile) for this i
+          }
         }
       }
       __syncthreads();
-      // 64 staged rows x 128 columns: 8 float4 per thread, a wave-instruction stores two 512-byte row segments
-      float* p = ob + (int64_t)(i * 32 + (tid >> 5)) * out_ld + (tid & 31) * 4;
+      // 64 staged rows x 128 columns: 8 float4 per thread, a wave-instruction stores two 512-byte row segments.
+      // Buffer stores: tile descriptor + one per-thread offset + a scalar row offset, like the loads.
       const float* sp = smem + (tid >> 5) * PD_BN + (tid & 31) * 4;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {  // staged row it*8 + tid/32 = tile row (it/4)*64 + i*32 + (it%4)*8 + tid/32
         const float4 v = *reinterpret_cast<const float4*>(sp + it * 8 * PD_BN);
-        *reinterpret_cast<float4*>(p + (int64_t)((it >> 2) * 64 + (it & 3) * 8) * out_ld) = v;
+        const pd_u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, orsrc, ovoff,
+                                               (((it >> 2) * 64 + i * 32 + (it & 3) * 8) * (int)out_ld) * 4, 0);
       }
       if (i == 0) __syncthreads();  // after i = 1 the next tile's first barrier stands between these reads and new writes
     }
@@ -394,7 +403,7 @@ static int launch_pairwise(const float* x, const float* y, float* out, int batch
 #define V3D_LAUNCH_PD(K_)                                                                                         \
   hipLaunchKernelGGL(K_, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, \
                      vec_out)
-  if (fast && vec_out && !(flags & V3D_PD_STRICT)) {
+  if (fast && vec_out && out_ld < (1 << 23) && !(flags & V3D_PD_STRICT)) {
     const int64_t tiles_x = ceil_div(M, PD_BN), tiles_y = ceil_div(N, PD_BM), total = tiles_x * tiles_y * batch;
     if (total <= (int64_t)INT32_MAX) {
       const dim3 sweep((unsigned)std::min<int64_t>(total, PD_SWEEP_WGS));
