@@ -597,6 +597,20 @@ __device__ __forceinline__ float row16_sum_f32(float v) {  // sum over each row 
   return v;
 }
 
+// The same for four values at once: the four chains alternate, so each DPP read finds its operand written three
+// instructions earlier and only the first needs the wait states (`s_nop 1`) that row16_sum_f32 pays per step.
+__device__ __forceinline__ void row16_sum4_f32(float (&v)[4]) {
+#define V3D_DPP_STEP4(CTRL_TEXT)                                                  \
+  "v_add_f32_dpp %0, %0, %0 " CTRL_TEXT " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %1, %1, %1 " CTRL_TEXT " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %2, %2, %2 " CTRL_TEXT " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %3, %3, %3 " CTRL_TEXT " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" V3D_DPP_STEP4("quad_perm:[1,0,3,2]") V3D_DPP_STEP4("quad_perm:[2,3,0,1]")
+                   V3D_DPP_STEP4("row_half_mirror") V3D_DPP_STEP4("row_mirror") "s_nop 1"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#undef V3D_DPP_STEP4
+}
+
 // Candidates kept per row for k requested neighbours.  The lists are selected on the expansion-form distance
 // (|x|^2 - 2xy + |y|^2 on the MFMA), whose rounding error (~1e-6 of |x|^2 + |y|^2) can swap neighbours whose exact
 // distances are closer than that; the finalize pass re-ranks on the exact difference form.  Keeping a few spare
@@ -619,34 +633,54 @@ __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __r
                                                                 int C, int k, int kout, int64_t index_offset, int vec4,
                                                                 float* __restrict__ out_d, int64_t* __restrict__ out_i) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
   if (row >= (int64_t)batch * N) return;
   const int b = (int)(row / N);
   const int idx = lane < k ? run_i[row * k + lane] : -1;
   float dist = INFINITY;
   const float* xr = x + row * C;
   if (vec4) {
-    // four neighbours at a time: a row of 16 lanes owns one neighbour and reads its features as 16-byte pieces;
-    // the four DPP steps that stay inside a row of 16 lanes leave every lane of the row with its neighbour's sum
+    // a row of 16 lanes owns one neighbour and reads its features as 16-byte pieces; the four DPP steps that stay
+    // inside a row of 16 lanes leave every lane of the row with its neighbour's sum.  Four such groups of four
+    // neighbours go together (16 feature rows requested at once).  The kernel is bound by instruction issue (~900 per
+    // query row at config 3 before, most of it bookkeeping): neighbour rows are addressed as a scalar cloud base + a
+    // 32-bit offset (vec4 implies M * C < 2^31), the DPP chains alternate, the square root is taken once at the end.
     const int l16 = lane & 15, grp = lane >> 4;
-    for (int j0 = 0; j0 < k; j0 += 4) {
-      const int ij = __shfl(idx, min(j0 + grp, 63), 64);
-      const bool live = (j0 + grp < k) && ij >= 0;
-      const float* yr = y + ((int64_t)b * M + (live ? ij : 0)) * C;
-      float part = 0.f;
-      for (int c = l16 * 4; c < C; c += 64) {
-        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
-        const float4 yv = *reinterpret_cast<const float4*>(yr + c);
-        const float d0 = xv.x - yv.x, d1 = xv.y - yv.y, d2 = xv.z - yv.z, d3 = xv.w - yv.w;
-        part = __builtin_fmaf(d0, d0, part);
-        part = __builtin_fmaf(d1, d1, part);
-        part = __builtin_fmaf(d2, d2, part);
-        part = __builtin_fmaf(d3, d3, part);
+    const float* yb = y + (int64_t)b * M * C;  // scalar registers
+    for (int j0 = 0; j0 < k; j0 += 16) {
+      unsigned yo[4];
+      bool live[4];
+      float part[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int jj = j0 + 4 * g + grp;
+        const int ij = __shfl(idx, min(jj, 63), 64);
+        live[g] = (jj < k) && ij >= 0;
+        yo[g] = (unsigned)(live[g] ? ij : 0) * (unsigned)C + (unsigned)(l16 * 4);
+        part[g] = 0.f;
       }
-      const float tot = row16_sum_f32(part);
-      const float mine = __shfl(live ? tot : INFINITY, (lane & 3) << 4, 64);  // neighbour j0 + (lane & 3)
-      if ((lane >> 2) == (j0 >> 2)) dist = sqrtf(mine);  // lane L keeps neighbour L
+      for (int c = l16 * 4, c0 = 0; c < C; c += 64, c0 += 64) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        float4 yv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yv[g] = *reinterpret_cast<const float4*>(yb + (yo[g] + (unsigned)c0));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float d0 = xv.x - yv[g].x, d1 = xv.y - yv[g].y, d2 = xv.z - yv[g].z, d3 = xv.w - yv[g].w;
+          part[g] = __builtin_fmaf(d0, d0, part[g]);
+          part[g] = __builtin_fmaf(d1, d1, part[g]);
+          part[g] = __builtin_fmaf(d2, d2, part[g]);
+          part[g] = __builtin_fmaf(d3, d3, part[g]);
+        }
+      }
+      row16_sum4_f32(part);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float mine = __shfl(live[g] ? part[g] : INFINITY, (lane & 3) << 4, 64);  // neighbour j0 + 4g + (lane & 3)
+        if ((lane >> 2) == ((j0 + 4 * g) >> 2)) dist = mine;                            // lane L keeps neighbour L's sum
+      }
     }
+    dist = sqrtf(dist);  // one square root per lane, after the sweep (sqrt(inf) = inf for the lanes without a neighbour)
     if (idx < 0) dist = INFINITY;
   } else {
     for (int j = 0; j < k; ++j) {
@@ -1005,13 +1039,15 @@ int v3d_knn_feat_f32(const float* x, const float* y, float* distances, int64_t* 
     rc = launch_status(what);
   }
   if (rc == 0) {
-    const int vec4 = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    const int vec4 = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+                     (int64_t)Mw * C <= (int64_t)INT32_MAX;
     if (large)
       hipLaunchKernelGGL(knn_feat_finalize_large_kernel, dim3((unsigned)rows), dim3(256), sel_bytes, stream, x, y,
                          ws.run_i, N, Mw, C, k, kout, index_offset, distances, indices);
     else
-      hipLaunchKernelGGL(knn_feat_finalize_kernel, dim3(row_blocks), dim3(256), 0, stream, x, y, ws.run_d, ws.run_i,
-                         batch, N, Mw, C, k, kout, index_offset, vec4, distances, indices);
+      // M == 0: every candidate is "none" and lanes without one read row 0 of the cloud -- give them x's, y may be null
+      hipLaunchKernelGGL(knn_feat_finalize_kernel, dim3(row_blocks), dim3(256), 0, stream, x, M > 0 ? y : x, ws.run_d,
+                         ws.run_i, batch, N, Mw, C, k, kout, index_offset, vec4, distances, indices);
     rc = launch_status(what);
   }
   if (own) {
