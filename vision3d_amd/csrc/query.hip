@@ -677,8 +677,9 @@ struct alignas(sizeof(T) * 2) HeapSlot {
 // the same LDS addresses and stores the same values (so each lane's own view of the heap stays coherent
 // without relying on another lane's store).
 template <typename T>
-__device__ __forceinline__ void heap_sift(HeapSlot<T>* h, int size, T vd, int vi) {
+__device__ __forceinline__ T heap_sift(HeapSlot<T>* h, int size, T vd, int vi) {  // returns the new root's distance
   int root = 0, child = 1;
+  T top = vd;
   while (child < size) {
     HeapSlot<T> c = h[child];
     if (child + 1 < size) {
@@ -690,6 +691,7 @@ __device__ __forceinline__ void heap_sift(HeapSlot<T>* h, int size, T vd, int vi
     }
     if (vd > c.d) break;  // :22 strict
     h[root] = c;
+    if (root == 0) top = c.d;
     root = child;
     child = root * 2 + 1;
   }
@@ -697,6 +699,7 @@ __device__ __forceinline__ void heap_sift(HeapSlot<T>* h, int size, T vd, int vi
   v.d = vd;
   v.i = vi;
   h[root] = v;
+  return top;
 }
 
 // ---- lane-distributed sorted list (ascending by (distance, arrival)), CAP = 64*R entries ----------------------
@@ -783,7 +786,11 @@ struct LaneList {
 
 // Exact replay of the reference heap for ONE query by the whole wave (used only when the fast path sees equal
 // distances among the k+1 nearest, where the heap's mechanics decide identity and order): supports are read from
-// global memory (L2-resident), candidates that beat the root are replayed in index order.
+// global memory (L2-resident) one chunk ahead, candidates that beat the root are replayed in index order.  A replay
+// is a serial chain (~190 insertions x 5 heap levels at N = 4096, k = 32, each level one LDS round trip): ~100 us on one
+// wave, and the launch ends when it does (tools/knn_tail_probe.py: 47 us without, 177 us with one replayed query at
+// B = 2).  The same heap spread over the lanes of the wave (v_readlane / v_writelane instead of LDS) was built and
+// measured slower (226 us): every step is a VALU -> SGPR -> VALU hop with its wait states.
 template <typename T>
 __device__ void knn_exact_replay(const T* __restrict__ s_cloud, int N, int k, T qx, T qy, T qz, HeapSlot<T>* h,
                                  T* __restrict__ od, int64_t* __restrict__ oi) {
@@ -796,17 +803,27 @@ __device__ void knn_exact_replay(const T* __restrict__ s_cloud, int N, int k, T 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   T root_d = static_cast<T>(1e10);
+  T cx, cy, cz;
+  {
+    const int jj = lane < N ? lane : 0;
+    cx = s_cloud[(int64_t)jj * 3 + 0];
+    cy = s_cloud[(int64_t)jj * 3 + 1];
+    cz = s_cloud[(int64_t)jj * 3 + 2];
+  }
   for (int c0 = 0; c0 < N; c0 += 64) {
-    const int j = c0 + lane;
-    const bool valid = j < N;
-    const int jj = valid ? j : 0;
-    const T d = sq_dist(qx, qy, qz, s_cloud[(int64_t)jj * 3 + 0], s_cloud[(int64_t)jj * 3 + 1],
-                        s_cloud[(int64_t)jj * 3 + 2]);
+    const bool valid = c0 + lane < N;
+    const T d = sq_dist(qx, qy, qz, cx, cy, cz);
+    {  // next chunk: in flight while this one's candidates go through the heap
+      const int jn = c0 + 64 + lane;
+      const int jj = jn < N ? jn : 0;
+      cx = s_cloud[(int64_t)jj * 3 + 0];
+      cy = s_cloud[(int64_t)jj * 3 + 1];
+      cz = s_cloud[(int64_t)jj * 3 + 2];
+    }
     unsigned long long m = __ballot(valid && d < root_d);  // :80 strict
     while (m) {
       const int l = __builtin_ffsll((long long)m) - 1;
-      heap_sift(h, k, read_lane(d, l), c0 + l);
-      root_d = h[0].d;
+      root_d = heap_sift(h, k, read_lane(d, l), c0 + l);  // (no dependent re-read of h[0])
       m = __ballot(valid && d < root_d) & ~((2ull << l) - 1ull);
     }
   }
@@ -895,6 +912,46 @@ __device__ __forceinline__ KnnWhere knn_where(int M, int N, const KnnPackPlan* _
   return w;
 }
 
+// Stage supports [t0, t0 + tcount) of a cloud and pad the tile's last chunk of 64 with points at +inf (their distance is
+// +inf or NaN: below no bound), so that the kNN loops read whole chunks without a validity test.  Whole workgroup.
+template <typename T>
+__device__ __forceinline__ void knn_stage_padded(const T* __restrict__ s_cloud, int t0, int tcount, T* tile) {
+  __syncthreads();
+  stage_supports_aos(s_cloud, t0, tcount, tile);
+  const int padded = (tcount + 63) & ~63;
+  for (int i = tcount * 3 + (int)threadIdx.x; i < padded * 3; i += kQueryThreads) tile[i] = static_cast<T>(INFINITY);
+  __syncthreads();
+}
+
+// Lane-minimum bound of a cloud for the QPW queries of a wave (every wave of the workgroup calls it: the tiles are
+// staged by the whole workgroup): capk[g] = an upper bound of query g's (k+1)-th smallest squared distance.
+template <typename T, int QPW, int TS>
+__device__ __forceinline__ void knn_lane_min_bound(const T* __restrict__ s_cloud, int N, int k, const T (&qx)[QPW],
+                                                   const T (&qy)[QPW], const T (&qz)[QPW], T* tile, int lane,
+                                                   T (&capk)[QPW]) {
+  static_assert(QPW % 2 == 0, "queries are taken in pairs");
+  T lmin[QPW];
+#pragma unroll
+  for (int g = 0; g < QPW; ++g) lmin[g] = INFINITY;
+  for (int t0 = 0; t0 < N; t0 += TS) {
+    const int tcount = min(TS, N - t0);
+    knn_stage_padded(s_cloud, t0, tcount, tile);
+    for (int c0 = 0; c0 < tcount; c0 += 64) {
+      const int j = c0 + lane;
+      const T sx = tile[j * 3 + 0], sy = tile[j * 3 + 1], sz = tile[j * 3 + 2];
+#pragma unroll
+      for (int g = 0; g < QPW; g += 2) {
+        T d0, d1;
+        sq_dist_pair(qx[g], qy[g], qz[g], qx[g + 1], qy[g + 1], qz[g + 1], sx, sy, sz, d0, d1);
+        lmin[g] = d0 < lmin[g] ? d0 : lmin[g];  // +inf and NaN never replace a minimum
+        lmin[g + 1] = d1 < lmin[g + 1] ? d1 : lmin[g + 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < QPW; ++g) capk[g] = kth_smallest_upper(lmin[g], k);
+}
+
 // Fast path: one wave serves QPW queries against LDS-staged supports.  Per query the k+1 best so far sit sorted in a
 // lane-distributed list; a chunk of 64 supports is filtered with one compare + ballot against the (k+1)-th best and
 // only the survivors are inserted (whole-wave DPP shift).  When the final k+1 distances are pairwise different the
@@ -934,45 +991,43 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
     }
   }
 
+  // Pre-pass over the WHOLE cloud: every lane takes the minimum distance of its own supports (j = lane mod 64); the
+  // (k+1)-th smallest of those 64 minima bounds the (k+1)-th smallest distance from above (64 distinct supports attain
+  // them) -- at N = 4096 about 1 % of the supports lie under it, so the search proper admits a few dozen candidates
+  // instead of the ~k ln(N/k) + stale ones of a bound that tightens as it goes.  Everything <= the bound is still
+  // admitted, in index order, so the k+1 best and their order among equals are unchanged.  One more distance pass
+  // (branch-free, ~6 VALU per query and chunk) for far fewer whole-wave insertions / merges.
+  const bool prepass = R == 1 && N >= 256;
+  if (prepass) knn_lane_min_bound<T, QPW, TS>(s_cloud, N, k, qx, qy, qz, tile, lane, capk);
   for (int t0 = 0; t0 < N; t0 += TS) {
     const int tcount = min(TS, N - t0);
-    __syncthreads();
-    stage_supports_aos(s_cloud, t0, tcount, tile);
-    __syncthreads();
-    if (t0 == 0 && R == 1 && tcount >= 256) {
-      // Pre-pass over the first tile: every lane takes the minimum distance of its own supports; the (k+1)-th
-      // smallest of those 64 minima bounds the (k+1)-th smallest distance from above (64 distinct supports attain
-      // them), usually tightly, so the list does not start by admitting whole chunks.  Everything <= the bound is still
-      // admitted, in index order, so the k+1 best and their order among equals are unchanged.
-      T lmin[QPW];
+    if (!(prepass && N <= TS)) knn_stage_padded(s_cloud, t0, tcount, tile);  // one tile: still staged from the pre-pass
+    // common chunk (no candidate for any query): packed distances, one compare per query against min(tau, capk)
+    T bound[QPW];
 #pragma unroll
-      for (int g = 0; g < QPW; ++g) lmin[g] = INFINITY;
-      for (int c0 = 0; c0 < tcount; c0 += 64) {
-        const int j = c0 + lane;
-        const bool valid = j < tcount;
-        const int jj = valid ? j : 0;
-        const T sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
-#pragma unroll
-        for (int g = 0; g < QPW; ++g) {
-          const T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
-          lmin[g] = (valid && d < lmin[g]) ? d : lmin[g];
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < QPW; ++g) capk[g] = kth_smallest_upper(lmin[g], k);
-    }
+    for (int g = 0; g < QPW; ++g) bound[g] = tau[g] < capk[g] ? tau[g] : capk[g];
     for (int c0 = 0; c0 < tcount; c0 += 64) {
       const int j = c0 + lane;
-      const bool valid = j < tcount;
-      const int jj = valid ? j : 0;
-      const T sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+      const T sx = tile[j * 3 + 0], sy = tile[j * 3 + 1], sz = tile[j * 3 + 2];  // tail lanes read the +inf padding
       const bool first_chunk = (t0 == 0 && c0 == 0);
+      T dq[QPW];
+#pragma unroll
+      for (int g = 0; g < QPW; g += 2)
+        sq_dist_pair(qx[g], qy[g], qz[g], qx[g + 1], qy[g + 1], qz[g + 1], sx, sy, sz, dq[g], dq[g + 1]);
+      unsigned long long pm[QPW], any = 0ull;
 #pragma unroll
       for (int g = 0; g < QPW; ++g) {
-        const T d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
+        pm[g] = __ballot(dq[g] <= bound[g]);
+        any |= pm[g];
+      }
+      if (any == 0ull) continue;  // one scalar test per chunk on the common path
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) {
+        const T d = dq[g];
+        if (pm[g] == 0ull) continue;
         if (first_chunk && tau[g] == sentinel && !(capk[g] < INFINITY)) {
           // empty list: rank-sort the whole chunk straight into it instead of 64 serial insertions
-          const bool real = valid && d < sentinel;
+          const bool real = d < sentinel;  // padding is +inf
           const T dm = real ? d : sentinel;
           const int im = real ? j : 0;
           int rank = 0;
@@ -983,15 +1038,17 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
           list[g].d[0] = lane_permute(dm, rank);
           list[g].i[0] = lane_permute(im, rank);
           tau[g] = list[g].at(k);
+          bound[g] = tau[g] < capk[g] ? tau[g] : capk[g];
           continue;
         }
-        unsigned long long m = __ballot(valid && d < tau[g] && d <= capk[g]);
+        unsigned long long m = __ballot(d < tau[g] && d <= capk[g]);  // padding (+inf) and NaN pass neither
         while (m) {
           const int l = __builtin_ffsll((long long)m) - 1;
           list[g].insert(read_lane(d, l), t0 + c0 + l, lane);
           tau[g] = list[g].at(k);
-          m = __ballot(valid && d < tau[g] && d <= capk[g]) & ~((2ull << l) - 1ull);
+          m = __ballot(d < tau[g] && d <= capk[g]) & ~((2ull << l) - 1ull);
         }
+        bound[g] = tau[g] < capk[g] ? tau[g] : capk[g];
       }
     }
   }
@@ -1068,39 +1125,39 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
     pending[g] = 0;
   }
 
+  // same whole-cloud pre-pass as knn_points_kernel: an upper bound of the (k+1)-th distance before the search proper
+  const bool prepass = N >= 256;
+  if (prepass) knn_lane_min_bound<float, QPW, TS>(s_cloud, N, k, qx, qy, qz, tile, lane, capk);
   for (int t0 = 0; t0 < N; t0 += TS) {
     const int tcount = min(TS, N - t0);
-    __syncthreads();
-    stage_supports_aos(s_cloud, t0, tcount, tile);
-    __syncthreads();
-    if (t0 == 0 && tcount >= 256) {  // same pre-pass as knn_points_kernel: an upper bound of the (k+1)-th distance
-      float lmin[QPW];
+    if (!(prepass && N <= TS)) knn_stage_padded(s_cloud, t0, tcount, tile);  // one tile: still staged from the pre-pass
+    // The common chunk holds no candidate for any of the wave's queries: it costs the packed distances, ONE float
+    // compare per query against min(pre-pass bound, distance of the current (k+1)-th key) and a scalar test.  Only a
+    // chunk that passes builds keys and applies the exact (distance, index) test.
+    float bound[QPW];
 #pragma unroll
-      for (int g = 0; g < QPW; ++g) lmin[g] = INFINITY;
-      for (int c0 = 0; c0 < tcount; c0 += 64) {
-        const int j = c0 + lane;
-        const bool valid = j < tcount;
-        const int jj = valid ? j : 0;
-        const float sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
-#pragma unroll
-        for (int g = 0; g < QPW; ++g) {
-          const float d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
-          lmin[g] = (valid && d < lmin[g]) ? d : lmin[g];
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < QPW; ++g) capk[g] = kth_smallest_upper(lmin[g], k);
-    }
+    for (int g = 0; g < QPW; ++g) bound[g] = fminf(capk[g], __uint_as_float((unsigned)(worst[g] >> 32)));
     for (int c0 = 0; c0 < tcount; c0 += 64) {
       const int j = c0 + lane;
-      const bool valid = j < tcount;
-      const int jj = valid ? j : 0;
-      const float sx = tile[jj * 3 + 0], sy = tile[jj * 3 + 1], sz = tile[jj * 3 + 2];
+      const float sx = tile[j * 3 + 0], sy = tile[j * 3 + 1], sz = tile[j * 3 + 2];  // tail lanes read the +inf padding
+      float dq[QPW];
+#pragma unroll
+      for (int g = 0; g < QPW; g += 2)
+        sq_dist_pair(qx[g], qy[g], qz[g], qx[g + 1], qy[g + 1], qz[g + 1], sx, sy, sz, dq[g], dq[g + 1]);
+      unsigned long long pm[QPW], any = 0ull;
 #pragma unroll
       for (int g = 0; g < QPW; ++g) {
-        const float d = sq_dist(qx[g], qy[g], qz[g], sx, sy, sz);
+        pm[g] = __ballot(dq[g] <= bound[g]);
+        any |= pm[g];
+      }
+      if (any == 0ull) continue;  // one scalar test per chunk on the common path
+#pragma unroll
+      for (int g = 0; g < QPW; ++g) {
+        const float d = dq[g];
+        if (pm[g] == 0ull) continue;
         const wkey_t key = ((wkey_t)__float_as_uint(d) << 32) | (unsigned)(t0 + j);
-        const bool take = valid && key < worst[g] && d <= capk[g];  // a NaN's pattern is above the sentinel's
+        // padding (+inf) and NaN patterns lie above the sentinel's, i.e. above every possible worst[g]
+        const bool take = key < worst[g] && d <= capk[g];
         const unsigned long long m = __ballot(take);
         if (m == 0ull) continue;
         wkey_t* buf = hits[wave][g];
@@ -1110,6 +1167,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
         if (pending[g] + n >= 64) {
           kept[g] = wave_merge_buffer(kept[g], buf, 64, lane);
           worst[g] = wave_lane64(kept[g], k);
+          bound[g] = fminf(capk[g], __uint_as_float((unsigned)(worst[g] >> 32)));
           if (take && dest >= 64) buf[dest - 64] = key;
           pending[g] += n - 64;
         } else {
