@@ -522,6 +522,40 @@ def test_pairwise_distance_vs_oracle(ext, oracle_mod, shape):
     assert np.all(np.abs(gs - want) <= _pd_tol(x, y) + 1e-7)
 
 
+@pytest.mark.parametrize("shape", [(2, 200, 260, 64), (1, 128, 132, 96), (3, 385, 512, 32), (1, 1000, 1028, 160),
+                                   (5, 129, 128, 64), (1, 2176, 1284, 64)])
+@pytest.mark.parametrize("squared", [True, False])
+@pytest.mark.parametrize("normalized", [False, True])
+def test_pairwise_distance_tile_sweep_edges(ext, shape, squared, normalized):
+    """The persistent tile sweep (N, M >= 128, C % 32 == 0, M % 4 == 0): last tiles moved back to end at the matrix edge
+    (cells shared with the neighbouring tile are computed twice, identically), several tiles per workgroup, both
+    epilogue forms.  Checked against the float64 evaluation of pairwise_distance.py:39-56, tolerance 1e-5 of the
+    operand scale as everywhere."""
+    from vision3d_amd import ops
+
+    b, n, m, c = shape
+    rng = np.random.default_rng(7 * n + m + c)
+    x = rng.standard_normal((b, n, c)).astype(np.float32)
+    y = rng.standard_normal((b, m, c)).astype(np.float32)
+    if normalized:
+        x /= np.linalg.norm(x, axis=-1, keepdims=True)
+        y /= np.linalg.norm(y, axis=-1, keepdims=True)
+    xd, yd = x.astype(np.float64), y.astype(np.float64)
+    xy = np.einsum("bnc,bmc->bnm", xd, yd)
+    want = (2.0 - 2.0 * xy) if normalized else ((xd ** 2).sum(-1)[:, :, None] - 2.0 * xy + (yd ** 2).sum(-1)[:, None, :])
+    want = np.maximum(want, 0.0)
+    got = N_(ops.pairwise_distance(T(x), T(y), normalized=normalized, squared=squared)).astype(np.float64)
+    if not squared:
+        got = got ** 2 - 1e-8  # sqrt(d + eps), eps = 1e-8
+    assert got.shape == want.shape
+    assert np.all(np.abs(got - want) <= _pd_tol(x, y) + 2e-7)
+    # a second call reproduces the first bit for bit (overlapping tiles write the same values, no order dependence)
+    again = N_(ops.pairwise_distance(T(x), T(y), normalized=normalized, squared=squared)).astype(np.float64)
+    if not squared:
+        again = again ** 2 - 1e-8
+    assert np.array_equal(got, again)
+
+
 def test_pairwise_distance_backward(ext):
     from vision3d_amd import ops
 
