@@ -194,6 +194,27 @@ def test_knn_points(ext, oracle_mod, dtype):
             assert np.array_equal(N_(d), wd), (name, k)
 
 
+@pytest.mark.parametrize("n", [63, 64, 255, 256, 1023, 1024, 1025, 2048, 2049])
+def test_knn_points_tile_and_prepass_boundaries(ext, oracle_mod, n):
+    """Support counts either side of the lane-minimum pre-pass threshold (256) and of the 1024-point LDS tile (one
+    tile: staged once for pre-pass and search; several: staged twice; last tile padded with +inf points), on the list
+    kernel (k = 8), the merge kernel (k = 32), the two-register list (k = 80) and fp64."""
+    rng = np.random.default_rng(n)
+    s = rng.random((2, n, 3), dtype=np.float32)
+    q = rng.random((2, 37, 3), dtype=np.float32)
+    for dtype, ks in ((np.float32, (8, 32, 80)), (np.float64, (8, 32))):
+        sd, qd = s.astype(dtype), q.astype(dtype)
+        for k in ks:
+            if k > n:
+                continue
+            wd, wi = oracle_mod.knn_points(qd, sd, k)
+            d = torch.zeros((2, 37, k), dtype=T(qd).dtype, device=DEV)
+            idx = torch.zeros((2, 37, k), dtype=torch.long, device=DEV)
+            ext.knn_points(T(qd), T(sd), d, idx, k)
+            assert np.array_equal(N_(idx), wi), (dtype, k)
+            assert np.array_equal(N_(d), wd), (dtype, k)
+
+
 def test_knn_points_k_too_large_raises(ext):
     q = torch.zeros((1, 2, 3), device=DEV)
     with pytest.raises(RuntimeError, match="V3D_ERR_K_TOO_LARGE"):
