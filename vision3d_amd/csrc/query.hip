@@ -784,16 +784,103 @@ struct LaneList {
   }
 };
 
+// The reference's max-heap (knn_points_cuda.cuh:16-28) for k <= 64 with ONE SLOT PER LANE, sifted by the whole wave
+// at once instead of level by level.  Replacing the root by v and sifting down moves along the "bigger child" path
+// from the root for as long as the child is >= v; on that path every mover takes its bigger child's slot and the first
+// non-mover takes v.  So: every lane fetches its two children (four ds_bpermute, one round trip), picks the bigger
+// (right only if strictly greater, :21); the path is followed with six dependent v_readlane (leaves point to
+// themselves); a lane on the path moves iff its bigger child is not below v (:22 strict; distances never increase
+// along the path, so the movers are a prefix of it); the lane on the path that does not move and whose parent does --
+// or the root -- receives v.  No LDS heap, no per-level branch: ~350 cycles per insertion against ~1,500 for the
+// branchy level-by-level walk that one wave alone executes at a branch every few instructions.
+template <typename T>
+__device__ __forceinline__ void lane_heap_sift(T& hd, int& hi, int size, T vd, int vi, int lane) {
+  const int c0 = 2 * lane + 1, c1 = c0 + 1;
+  const T d0 = __shfl(hd, c0 & 63, 64), d1 = __shfl(hd, c1 & 63, 64);
+  const int i0 = __shfl(hi, c0 & 63, 64), i1 = __shfl(hi, c1 & 63, 64);
+  const bool has0 = c0 < size, has1 = c1 < size;
+  const bool right = has1 && (d1 > d0);  // :21 strict
+  const int big = has0 ? (right ? c1 : c0) : lane;
+  const T cd = right ? d1 : d0;
+  const int ci = right ? i1 : i0;
+  int p = 0;
+  unsigned long long path = 1ull;  // bit n: slot n lies on the bigger-child path from the root
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {  // 64 slots: at most 6 levels below the root
+    p = __builtin_amdgcn_readlane(big, p);
+    path |= 1ull << p;
+  }
+  const bool on_path = (path >> lane) & 1ull;
+  const bool moves = on_path && has0 && !(vd > cd);  // :22 strict
+  const unsigned long long moved = __ballot(moves);
+  const bool parent_moved = lane == 0 || ((moved >> ((lane - 1) >> 1)) & 1ull);
+  const bool takes_v = on_path && !moves && parent_moved;
+  hd = moves ? cd : (takes_v ? vd : hd);
+  hi = moves ? ci : (takes_v ? vi : hi);
+}
+
+// Replay for k <= 64 on the lane heap: the heap, the heap sort and the output never leave the registers.
+template <typename T>
+__device__ void knn_exact_replay_lanes(const T* __restrict__ s_cloud, int N, int k, T qx, T qy, T qz,
+                                       T* __restrict__ od, int64_t* __restrict__ oi) {
+  const int lane = threadIdx.x & 63;
+  T hd = static_cast<T>(1e10);  // knn_points_cuda.cuh:70-73
+  int hi = 0;
+  T root_d = static_cast<T>(1e10);
+  T cx, cy, cz;
+  {
+    const int jj = lane < N ? lane : 0;
+    cx = s_cloud[(int64_t)jj * 3 + 0];
+    cy = s_cloud[(int64_t)jj * 3 + 1];
+    cz = s_cloud[(int64_t)jj * 3 + 2];
+  }
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const bool valid = c0 + lane < N;
+    const T d = sq_dist(qx, qy, qz, cx, cy, cz);
+    {  // next chunk: in flight while this one's candidates go through the heap
+      const int jn = c0 + 64 + lane;
+      const int jj = jn < N ? jn : 0;
+      cx = s_cloud[(int64_t)jj * 3 + 0];
+      cy = s_cloud[(int64_t)jj * 3 + 1];
+      cz = s_cloud[(int64_t)jj * 3 + 2];
+    }
+    unsigned long long m = __ballot(valid && d < root_d);  // :80 strict
+    while (m) {
+      const int l = __builtin_ffsll((long long)m) - 1;
+      lane_heap_sift(hd, hi, k, read_lane(d, l), c0 + l, lane);
+      root_d = read_lane(hd, 0);
+      m = __ballot(valid && d < root_d) & ~((2ull << l) - 1ull);
+    }
+  }
+  for (int i = k - 1; i > 0; --i) {  // heap_sort :30-37: root <-> slot i, then sift the old slot i down a heap of i
+    const T top_d = read_lane(hd, 0), last_d = read_lane(hd, i);
+    const int top_i = __builtin_amdgcn_readlane(hi, 0), last_i = __builtin_amdgcn_readlane(hi, i);
+    if (lane == i) {
+      hd = top_d;
+      hi = top_i;
+    }
+    lane_heap_sift(hd, hi, i, last_d, last_i, lane);
+  }
+  if (lane < k) {  // :88-91
+    od[lane] = sqrt(hd);
+    oi[lane] = (int64_t)hi;
+  }
+}
+
 // Exact replay of the reference heap for ONE query by the whole wave (used only when the fast path sees equal
 // distances among the k+1 nearest, where the heap's mechanics decide identity and order): supports are read from
 // global memory (L2-resident) one chunk ahead, candidates that beat the root are replayed in index order.  A replay
 // is a serial chain (~190 insertions x 5 heap levels at N = 4096, k = 32, each level one LDS round trip): ~100 us on one
 // wave, and the launch ends when it does (tools/knn_tail_probe.py: 47 us without, 177 us with one replayed query at
-// B = 2).  The same heap spread over the lanes of the wave (v_readlane / v_writelane instead of LDS) was built and
-// measured slower (226 us): every step is a VALU -> SGPR -> VALU hop with its wait states.
+// B = 2).  k <= 64 takes the lane heap above; this LDS heap serves 64 < k <= 100.  (A lane heap walked level by level
+// with v_readlane / v_writelane was measured slower than LDS, 226 us: every step a VALU -> SGPR -> VALU hop.)
 template <typename T>
 __device__ void knn_exact_replay(const T* __restrict__ s_cloud, int N, int k, T qx, T qy, T qz, HeapSlot<T>* h,
                                  T* __restrict__ od, int64_t* __restrict__ oi) {
+  if (k <= 64) {  // wave-uniform
+    knn_exact_replay_lanes(s_cloud, N, k, qx, qy, qz, od, oi);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   for (int n = lane; n < k; n += 64) {  // knn_points_cuda.cuh:70-73
     HeapSlot<T> v;
@@ -1096,7 +1183,6 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
                                                                          int N_arg, int k,
                                                                          const KnnPackPlan* __restrict__ plan, int B) {
   __shared__ __align__(16) float tile[TS * 3];
-  __shared__ HeapSlot<float> heaps[kWavesPerBlock * V3D_KNN_MAX_K];
   __shared__ wkey_t hits[kWavesPerBlock][QPW][64];
   const KnnWhere where = knn_where<PACK>(M_arg, N_arg, plan, B);
   if (!where.live) return;  // the whole workgroup
@@ -1188,7 +1274,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
     // equal real distances among ranks 0..k -> the heap's mechanics matter
     const unsigned long long ties = __ballot(lane >= 1 && lane <= k && d == below && d < sentinel);
     if (ties != 0ull) {
-      knn_exact_replay(s_cloud, N, k, qx[g], qy[g], qz[g], heaps + wave * V3D_KNN_MAX_K, od, oi);
+      knn_exact_replay_lanes(s_cloud, N, k, qx[g], qy[g], qz[g], od, oi);  // k + 1 <= 64 here
     } else if (lane < k) {
       od[lane] = sqrtf(d);  // :90
       oi[lane] = (int64_t)(unsigned)kept[g];
