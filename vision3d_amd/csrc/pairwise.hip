@@ -345,7 +345,7 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     if (tid < 128) x2s[tid] = normalized ? 2.0f : norm; else y2s[tid - 128] = normalized ? 0.0f : norm;
     __syncthreads();  // norms visible; operand tiles free for the output staging
 
-    // the tile's 128 output rows as a buffer: 128 * out_ld * 4 bytes < 2^32 (out_ld < 2^23 on this path)
+    // the tile's 128 output rows as a buffer: < 2^31 bytes (out_ld <= 2^21 on this path)
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         out + ((int64_t)cur.b * N + cur.row0) * out_ld + cur.col0, 0, (PD_BM - 1) * (int)out_ld * 4 + PD_BN * 4, 0x00020000);
 #pragma unroll
@@ -403,7 +403,8 @@ static int launch_pairwise(const float* x, const float* y, float* out, int batch
 #define V3D_LAUNCH_PD(K_)                                                                                         \
   hipLaunchKernelGGL(K_, grid, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C, y_batch_stride, out_ld, flags, eps, \
                      vec_out)
-  if (fast && vec_out && out_ld < (1 << 23) && !(flags & V3D_PD_STRICT)) {
+  // out_ld <= 2^21: the 128 output rows of a tile (127 * out_ld * 4 + 512 bytes) and every row offset stay below 2^31
+  if (fast && vec_out && out_ld <= (1 << 21) && !(flags & V3D_PD_STRICT)) {
     const int64_t tiles_x = ceil_div(M, PD_BN), tiles_y = ceil_div(N, PD_BM), total = tiles_x * tiles_y * batch;
     if (total <= (int64_t)INT32_MAX) {
       const dim3 sweep((unsigned)std::min<int64_t>(total, PD_SWEEP_WGS));
