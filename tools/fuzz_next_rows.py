@@ -23,7 +23,30 @@ def table(rng, m, k, n):
 
 
 def one_case(rng, i):
-    kind = i % 16
+    kind = i % 17
+    if kind == 16:  # pairwise distance: the tile sweep (whole tiles, shifted edge tiles), the one-tile kernels, every flag
+        b = int(rng.integers(1, 4))
+        n, m = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+        c = int(rng.choice([3, 32, 33, 64, 96, 160]))
+        normalized, squared, strict = bool(rng.integers(2)), bool(rng.integers(2)), rng.integers(4) == 0
+        x = rng.standard_normal((b, n, c)).astype(np.float32)
+        y = rng.standard_normal((b, m, c)).astype(np.float32)
+        if normalized:
+            x /= np.maximum(np.linalg.norm(x, axis=-1, keepdims=True), 1e-6)
+            y /= np.maximum(np.linalg.norm(y, axis=-1, keepdims=True), 1e-6)
+        xd, yd = x.astype(np.float64), y.astype(np.float64)
+        xy = np.einsum("bnc,bmc->bnm", xd, yd)
+        sq = (xd ** 2).sum(-1)[:, :, None] - 2.0 * xy + (yd ** 2).sum(-1)[:, None, :]
+        if strict:
+            want = np.maximum(sq, 0.0)  # the difference form ignores `normalized`
+        else:
+            want = np.maximum((2.0 - 2.0 * xy) if normalized else sq, 0.0)
+        got = N_(ops.pairwise_distance(T(x), T(y), normalized=normalized, squared=squared, strict=strict)).astype(np.float64)
+        if not squared:
+            got = got ** 2 - (0.0 if strict else 1e-8)
+        tol = 1e-5 * ((x.astype(np.float64) ** 2).sum(-1)[:, :, None] + (y.astype(np.float64) ** 2).sum(-1)[:, None, :]) + 3e-7
+        ok = got.shape == want.shape and bool(np.all(np.abs(got - want) <= tol))
+        return ok, f"pairwise b{b} n{n} m{m} c{c} norm{normalized} sq{squared} strict{strict}"
     if kind == 12:  # backward scatters (scatter.hip): every channel-tile / chunk geometry, both dtypes, skewed indices
         dt = np.float32 if rng.integers(4) else np.float64
         b, c = int(rng.integers(1, 4)), int(rng.integers(1, 40))
