@@ -460,6 +460,10 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   // consecutive columns of each 256-column slab; rows are 16-byte aligned and padded to a multiple of 128 columns).
   float cap = INFINITY;
   const int ntile = (ncols + 1023) >> 10;
+  float4 keep[4];  // a row of one tile (<= 1024 columns: config 3, every chunk of a wide search) stays in registers
+                   // between the two passes: the selection is bound by its reads, and this halves them
+#pragma unroll
+  for (int u = 0; u < 4; ++u) keep[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (first_chunk && ncols >= 256) {
     float lmin = INFINITY;
     for (int t = 0; t < ntile; ++t) {
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
         const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) lmin = fminf(lmin, c + q < ncols ? e[q] : INFINITY);
+        keep[u] = v[u];  // (the last tile's; used only when it is the only one)
       }
     }
     // k-th smallest of the 64 minima (distances are >= 0, so the IEEE pattern orders like an integer): bit-wise binary
@@ -498,10 +503,15 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
     int count = 0;
     for (int t = 0; t < ntile && count <= kTopkCand; ++t) {
       float4 v[4];
+      if (ntile == 1) {  // wave-uniform
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = (t << 10) + ((u << 6) + lane) * 4;
-        v[u] = *reinterpret_cast<const float4*>(drow + (c < ncols ? c : 0));
+        for (int u = 0; u < 4; ++u) v[u] = keep[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = (t << 10) + ((u << 6) + lane) * 4;
+          v[u] = *reinterpret_cast<const float4*>(drow + (c < ncols ? c : 0));
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
