@@ -666,42 +666,6 @@ __global__ __launch_bounds__(kQueryThreads) void radius_count_kernel(const float
 // ------------------------------------------------------------------------------------------------------
 // knn_points
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
-struct alignas(sizeof(T) * 2) HeapSlot {
-  T d;
-  int i;
-};
-
-// Sift `v` down from the root of a max-heap of `size` slots: knn_points_cuda.cuh:16-28 with the swaps
-// replaced by "move the child up, carry the value" (same final array).  Wave-uniform: every lane runs it on
-// the same LDS addresses and stores the same values (so each lane's own view of the heap stays coherent
-// without relying on another lane's store).
-template <typename T>
-__device__ __forceinline__ T heap_sift(HeapSlot<T>* h, int size, T vd, int vi) {  // returns the new root's distance
-  int root = 0, child = 1;
-  T top = vd;
-  while (child < size) {
-    HeapSlot<T> c = h[child];
-    if (child + 1 < size) {
-      HeapSlot<T> c1 = h[child + 1];
-      if (c1.d > c.d) {  // :21 strict
-        c = c1;
-        ++child;
-      }
-    }
-    if (vd > c.d) break;  // :22 strict
-    h[root] = c;
-    if (root == 0) top = c.d;
-    root = child;
-    child = root * 2 + 1;
-  }
-  HeapSlot<T> v;
-  v.d = vd;
-  v.i = vi;
-  h[root] = v;
-  return top;
-}
-
 // ---- lane-distributed sorted list (ascending by (distance, arrival)), CAP = 64*R entries ----------------------
 __device__ __forceinline__ int shr1_fill(int v, int fill) {  // lane l <- lane l-1, lane 0 <- fill
   return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -784,7 +748,8 @@ struct LaneList {
   }
 };
 
-// The reference's max-heap (knn_points_cuda.cuh:16-28) for k <= 64 with ONE SLOT PER LANE, sifted by the whole wave
+// The reference's max-heap (knn_points_cuda.cuh:16-28) with its slots IN THE LANES (one per lane up to k = 64, two up
+// to the reference's limit of 100), sifted by the whole wave
 // at once instead of level by level.  Replacing the root by v and sifting down moves along the "bigger child" path
 // from the root for as long as the child is >= v; on that path every mover takes its bigger child's slot and the first
 // non-mover takes v.  So: every lane fetches its two children (four ds_bpermute, one round trip), picks the bigger
@@ -793,39 +758,75 @@ struct LaneList {
 // along the path, so the movers are a prefix of it); the lane on the path that does not move and whose parent does --
 // or the root -- receives v.  No LDS heap, no per-level branch: ~350 cycles per insertion against ~1,500 for the
 // branchy level-by-level walk that one wave alone executes at a branch every few instructions.
-template <typename T>
-__device__ __forceinline__ void lane_heap_sift(T& hd, int& hi, int size, T vd, int vi, int lane) {
-  const int c0 = 2 * lane + 1, c1 = c0 + 1;
-  const T d0 = __shfl(hd, c0 & 63, 64), d1 = __shfl(hd, c1 & 63, 64);
-  const int i0 = __shfl(hi, c0 & 63, 64), i1 = __shfl(hi, c1 & 63, 64);
+template <typename T, int R>
+__device__ __forceinline__ void lane_heap_sift(T (&hd)[R], int (&hi)[R], int size, T vd, int vi, int lane) {
+  // slot n = lane n & 63 of register n >> 6 (R = 2: up to 128 slots; slots 64.. have no children below 128: leaves)
+  const int c0 = 2 * lane + 1, c1 = c0 + 1;  // children of this lane's register-0 slot
+  T d0 = __shfl(hd[0], c0 & 63, 64), d1 = __shfl(hd[0], c1 & 63, 64);
+  int i0 = __shfl(hi[0], c0 & 63, 64), i1 = __shfl(hi[0], c1 & 63, 64);
+  if constexpr (R == 2) {
+    const T e0 = __shfl(hd[1], c0 & 63, 64), e1 = __shfl(hd[1], c1 & 63, 64);
+    const int j0 = __shfl(hi[1], c0 & 63, 64), j1 = __shfl(hi[1], c1 & 63, 64);
+    d0 = c0 >= 64 ? e0 : d0;
+    i0 = c0 >= 64 ? j0 : i0;
+    d1 = c1 >= 64 ? e1 : d1;
+    i1 = c1 >= 64 ? j1 : i1;
+  }
   const bool has0 = c0 < size, has1 = c1 < size;
   const bool right = has1 && (d1 > d0);  // :21 strict
   const int big = has0 ? (right ? c1 : c0) : lane;
   const T cd = right ? d1 : d0;
   const int ci = right ? i1 : i0;
   int p = 0;
-  unsigned long long path = 1ull;  // bit n: slot n lies on the bigger-child path from the root
+  unsigned long long path[R];  // bit n & 63 of word n >> 6: slot n lies on the bigger-child path from the root
+  path[0] = 1ull;
+  if constexpr (R == 2) path[1] = 0ull;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {  // 64 slots: at most 6 levels below the root
-    p = __builtin_amdgcn_readlane(big, p);
-    path |= 1ull << p;
+  for (int j = 0; j < 6; ++j) {  // slots 0 .. 126: at most 6 levels below the root
+    if constexpr (R == 2) {
+      p = p < 64 ? __builtin_amdgcn_readlane(big, p & 63) : p;  // a register-1 slot is a leaf
+      if (p < 64) path[0] |= 1ull << p; else path[1] |= 1ull << (p - 64);
+    } else {
+      p = __builtin_amdgcn_readlane(big, p);
+      path[0] |= 1ull << p;
+    }
   }
-  const bool on_path = (path >> lane) & 1ull;
+  const bool on_path = (path[0] >> lane) & 1ull;
   const bool moves = on_path && has0 && !(vd > cd);  // :22 strict
   const unsigned long long moved = __ballot(moves);
   const bool parent_moved = lane == 0 || ((moved >> ((lane - 1) >> 1)) & 1ull);
   const bool takes_v = on_path && !moves && parent_moved;
-  hd = moves ? cd : (takes_v ? vd : hd);
-  hi = moves ? ci : (takes_v ? vi : hi);
+  hd[0] = moves ? cd : (takes_v ? vd : hd[0]);
+  hi[0] = moves ? ci : (takes_v ? vi : hi[0]);
+  if constexpr (R == 2) {  // slot 64 + lane: never a mover; its parent is slot (63 + lane) / 2 of register 0
+    const bool takes_v1 = ((path[1] >> lane) & 1ull) && ((moved >> ((63 + lane) >> 1)) & 1ull);
+    hd[1] = takes_v1 ? vd : hd[1];
+    hi[1] = takes_v1 ? vi : hi[1];
+  }
 }
 
-// Replay for k <= 64 on the lane heap: the heap, the heap sort and the output never leave the registers.
-template <typename T>
+// Replay on the lane heap (R = 1: k <= 64, R = 2: k <= 127): the heap, the heap sort and the output never leave the
+// registers.
+template <typename T, int R>
 __device__ void knn_exact_replay_lanes(const T* __restrict__ s_cloud, int N, int k, T qx, T qy, T qz,
                                        T* __restrict__ od, int64_t* __restrict__ oi) {
   const int lane = threadIdx.x & 63;
-  T hd = static_cast<T>(1e10);  // knn_points_cuda.cuh:70-73
-  int hi = 0;
+  T hd[R];
+  int hi[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    hd[r] = static_cast<T>(1e10);  // knn_points_cuda.cuh:70-73
+    hi[r] = 0;
+  }
+  auto slot_d = [&](int n) {  // n wave-uniform
+    if constexpr (R == 2) return n < 64 ? read_lane(hd[0], n & 63) : read_lane(hd[1], n & 63);
+    else return read_lane(hd[0], n);
+  };
+  auto slot_i = [&](int n) {
+    if constexpr (R == 2)
+      return n < 64 ? __builtin_amdgcn_readlane(hi[0], n & 63) : __builtin_amdgcn_readlane(hi[1], n & 63);
+    else return __builtin_amdgcn_readlane(hi[0], n);
+  };
   T root_d = static_cast<T>(1e10);
   T cx, cy, cz;
   {
@@ -847,85 +848,50 @@ __device__ void knn_exact_replay_lanes(const T* __restrict__ s_cloud, int N, int
     unsigned long long m = __ballot(valid && d < root_d);  // :80 strict
     while (m) {
       const int l = __builtin_ffsll((long long)m) - 1;
-      lane_heap_sift(hd, hi, k, read_lane(d, l), c0 + l, lane);
-      root_d = read_lane(hd, 0);
+      lane_heap_sift<T, R>(hd, hi, k, read_lane(d, l), c0 + l, lane);
+      root_d = read_lane(hd[0], 0);
       m = __ballot(valid && d < root_d) & ~((2ull << l) - 1ull);
     }
   }
   for (int i = k - 1; i > 0; --i) {  // heap_sort :30-37: root <-> slot i, then sift the old slot i down a heap of i
-    const T top_d = read_lane(hd, 0), last_d = read_lane(hd, i);
-    const int top_i = __builtin_amdgcn_readlane(hi, 0), last_i = __builtin_amdgcn_readlane(hi, i);
-    if (lane == i) {
-      hd = top_d;
-      hi = top_i;
+    const T top_d = slot_d(0), last_d = slot_d(i);
+    const int top_i = slot_i(0), last_i = slot_i(i);
+    if (lane == (i & 63)) {
+      if (R == 1 || i < 64) {
+        hd[0] = top_d;
+        hi[0] = top_i;
+      } else {
+        hd[R - 1] = top_d;
+        hi[R - 1] = top_i;
+      }
     }
-    lane_heap_sift(hd, hi, i, last_d, last_i, lane);
+    lane_heap_sift<T, R>(hd, hi, i, last_d, last_i, lane);
   }
   if (lane < k) {  // :88-91
-    od[lane] = sqrt(hd);
-    oi[lane] = (int64_t)hi;
+    od[lane] = sqrt(hd[0]);
+    oi[lane] = (int64_t)hi[0];
+  }
+  if constexpr (R == 2) {
+    if (lane + 64 < k) {
+      od[lane + 64] = sqrt(hd[1]);
+      oi[lane + 64] = (int64_t)hi[1];
+    }
   }
 }
 
 // Exact replay of the reference heap for ONE query by the whole wave (used only when the fast path sees equal
 // distances among the k+1 nearest, where the heap's mechanics decide identity and order): supports are read from
-// global memory (L2-resident) one chunk ahead, candidates that beat the root are replayed in index order.  A replay
-// is a serial chain (~190 insertions x 5 heap levels at N = 4096, k = 32, each level one LDS round trip): ~100 us on one
-// wave, and the launch ends when it does (tools/knn_tail_probe.py: 47 us without, 177 us with one replayed query at
-// B = 2).  k <= 64 takes the lane heap above; this LDS heap serves 64 < k <= 100.  (A lane heap walked level by level
-// with v_readlane / v_writelane was measured slower than LDS, 226 us: every step a VALU -> SGPR -> VALU hop.)
+// global memory (L2-resident) one chunk ahead, candidates that beat the root are replayed in index order.  A replay is
+// a serial chain (~190 insertions at N = 4096, k = 32) on one wave and the launch ends when it does
+// (tools/knn_tail_probe.py), hence the lane heap: with the heap in LDS and a level-by-level walk it took ~130 us
+// (k = 32) / ~220 us (k = 100).  (A lane heap walked level by level with v_readlane / v_writelane was slower than
+// LDS: every step a VALU -> SGPR -> VALU hop.)
 template <typename T>
-__device__ void knn_exact_replay(const T* __restrict__ s_cloud, int N, int k, T qx, T qy, T qz, HeapSlot<T>* h,
-                                 T* __restrict__ od, int64_t* __restrict__ oi) {
-  if (k <= 64) {  // wave-uniform
-    knn_exact_replay_lanes(s_cloud, N, k, qx, qy, qz, od, oi);
-    return;
-  }
-  const int lane = threadIdx.x & 63;
-  for (int n = lane; n < k; n += 64) {  // knn_points_cuda.cuh:70-73
-    HeapSlot<T> v;
-    v.d = static_cast<T>(1e10);
-    v.i = 0;
-    h[n] = v;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  T root_d = static_cast<T>(1e10);
-  T cx, cy, cz;
-  {
-    const int jj = lane < N ? lane : 0;
-    cx = s_cloud[(int64_t)jj * 3 + 0];
-    cy = s_cloud[(int64_t)jj * 3 + 1];
-    cz = s_cloud[(int64_t)jj * 3 + 2];
-  }
-  for (int c0 = 0; c0 < N; c0 += 64) {
-    const bool valid = c0 + lane < N;
-    const T d = sq_dist(qx, qy, qz, cx, cy, cz);
-    {  // next chunk: in flight while this one's candidates go through the heap
-      const int jn = c0 + 64 + lane;
-      const int jj = jn < N ? jn : 0;
-      cx = s_cloud[(int64_t)jj * 3 + 0];
-      cy = s_cloud[(int64_t)jj * 3 + 1];
-      cz = s_cloud[(int64_t)jj * 3 + 2];
-    }
-    unsigned long long m = __ballot(valid && d < root_d);  // :80 strict
-    while (m) {
-      const int l = __builtin_ffsll((long long)m) - 1;
-      root_d = heap_sift(h, k, read_lane(d, l), c0 + l);  // (no dependent re-read of h[0])
-      m = __ballot(valid && d < root_d) & ~((2ull << l) - 1ull);
-    }
-  }
-  for (int i = k - 1; i > 0; --i) {  // heap_sort :30-37
-    const HeapSlot<T> top = h[0];
-    const HeapSlot<T> last = h[i];
-    h[i] = top;
-    heap_sift(h, i, last.d, last.i);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  for (int n = lane; n < k; n += 64) {  // :88-91
-    const HeapSlot<T> v = h[n];
-    od[n] = sqrt(v.d);
-    oi[n] = (int64_t)v.i;
-  }
+__device__ void knn_exact_replay(const T* __restrict__ s_cloud, int N, int k, T qx, T qy, T qz, T* __restrict__ od,
+                                 int64_t* __restrict__ oi) {
+  static_assert(V3D_KNN_MAX_K <= 127, "two slots per lane");
+  if (k <= 64) knn_exact_replay_lanes<T, 1>(s_cloud, N, k, qx, qy, qz, od, oi);  // wave-uniform
+  else knn_exact_replay_lanes<T, 2>(s_cloud, N, k, qx, qy, qz, od, oi);
 }
 
 // ---- pack mode (ops/knn.py:110-145): clouds of different sizes concatenated ------------------------------------------
@@ -1049,7 +1015,6 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
                                                                    int M_arg, int N_arg, int k,
                                                                    const KnnPackPlan* __restrict__ plan, int B) {
   __shared__ __align__(16) T tile[TS * 3];
-  __shared__ HeapSlot<T> heaps[kWavesPerBlock * V3D_KNN_MAX_K];
   const KnnWhere where = knn_where<PACK>(M_arg, N_arg, plan, B);
   if (!where.live) return;  // the whole workgroup
   const int M = where.M, N = where.N;
@@ -1156,7 +1121,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
       prev_last = read_lane(list[g].d[r], 63);
     }
     if (ties != 0ull) {
-      knn_exact_replay(s_cloud, N, k, qx[g], qy[g], qz[g], heaps + wave * V3D_KNN_MAX_K, od, oi);
+      knn_exact_replay(s_cloud, N, k, qx[g], qy[g], qz[g], od, oi);
     } else {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -1274,7 +1239,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
     // equal real distances among ranks 0..k -> the heap's mechanics matter
     const unsigned long long ties = __ballot(lane >= 1 && lane <= k && d == below && d < sentinel);
     if (ties != 0ull) {
-      knn_exact_replay_lanes(s_cloud, N, k, qx[g], qy[g], qz[g], od, oi);  // k + 1 <= 64 here
+      knn_exact_replay_lanes<float, 1>(s_cloud, N, k, qx[g], qy[g], qz[g], od, oi);  // k + 1 <= 64 here
     } else if (lane < k) {
       od[lane] = sqrtf(d);  // :90
       oi[lane] = (int64_t)(unsigned)kept[g];
