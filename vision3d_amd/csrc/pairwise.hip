@@ -271,7 +271,18 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // loads issued before them), instead of ending and holding its CU slot until the last store is acknowledged.  With
 // one tile per workgroup the workgroups of a CU run in lock-step (they start together and take equally long), so
 // their k loops and their epilogues did not overlap: total time was the SUM of the k-loop time and the store time.
-constexpr int PD_SWEEP_WGS = 4 * 256;  // MI355X: 256 CUs x four workgroups (128 registers, 34 KB of LDS each)
+constexpr int PD_SWEEP_WGS_PER_CU = 4;  // 128 registers, 34 KB of LDS each (MI355X: 256 CUs -> 1024 workgroups)
+static int pd_sweep_workgroups() {     // per current device; a partitioned GPU shows fewer CUs
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PD_SWEEP_WGS_PER_CU * 256;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = PD_SWEEP_WGS_PER_CU * cus;
+  }
+  return cached[dev];
+}
 struct PdTileAt {
   int b, row0, col0;
 };
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const float* const y2p = y2s + wc * 64 + l31;
   const unsigned ovoff = ((tid >> 5) * (unsigned)out_ld + (tid & 31) * 4) * 4u;  // this thread's cell of an 8-row group
 
-  int t = blockIdx.x;  // < total: the grid is min(total, PD_SWEEP_WGS)
+  int t = blockIdx.x;  // < total: the grid is min(total, four workgroups per CU)
   PdTileAt at = pd_tile_at(t, tiles_x, tiles_y, N, M);
   PdTileSrc tx = pd_tile_src(x + (int64_t)at.b * N * C, C, at.row0);
   PdTileSrc ty = pd_tile_src(y + (int64_t)at.b * y_batch_stride, C, at.col0);
@@ -407,7 +418,7 @@ static int launch_pairwise(const float* x, const float* y, float* out, int batch
   if (fast && vec_out && out_ld <= (1 << 21) && !(flags & V3D_PD_STRICT)) {
     const int64_t tiles_x = ceil_div(M, PD_BN), tiles_y = ceil_div(N, PD_BM), total = tiles_x * tiles_y * batch;
     if (total <= (int64_t)INT32_MAX) {
-      const dim3 sweep((unsigned)std::min<int64_t>(total, PD_SWEEP_WGS));
+      const dim3 sweep((unsigned)std::min<int64_t>(total, pd_sweep_workgroups()));
       if (flags & V3D_PD_SQRT)
         hipLaunchKernelGGL(pairwise_distance_sweep_kernel<true>, sweep, dim3(PD_THREADS), 0, stream, x, y, out, N, M, C,
                            y_batch_stride, out_ld, flags, eps, (int)tiles_x, (int)tiles_y, (int)total);
