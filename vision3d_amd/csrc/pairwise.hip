@@ -267,8 +267,10 @@ __global__ __launch_bounds__(PD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // The MFMA form for whole tiles and vector stores, as a sweep: at most four workgroups per CU, each taking tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ...  What the one-tile-per-workgroup form cannot do: (1) the first slab of the
 // next tile is requested during the last slab of this one, so no tile starts by waiting for memory; (2) the epilogue's
-// global stores are only ISSUED -- the workgroup goes on with the next tile while they drain (its next wait is for
-// loads issued before them), instead of ending and holding its CU slot until the last store is acknowledged.  With
+// global stores are only ISSUED -- the workgroup goes on with the next tile while they drain, instead of ending and
+// holding its CU slot until the last store is acknowledged.  (As compiled, the wait in front of the next tile's first
+// LDS stores is the loop's vmcnt(<= 7), which the stores issued after those loads fall under too: the wave stalls
+// there until its own stores are acknowledged, the other three workgroups of the CU carry on.  DESIGN.md section 9.)  With
 // one tile per workgroup the workgroups of a CU run in lock-step (they start together and take equally long), so
 // their k loops and their epilogues did not overlap: total time was the SUM of the k-loop time and the store time.
 constexpr int PD_SWEEP_WGS_PER_CU = 4;  // 128 registers, 34 KB of LDS each (MI355X: 256 CUs -> 1024 workgroups)
