@@ -4,7 +4,8 @@ from vision3d_amd import ext
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
 from opbench import timeit
 g = torch.Generator().manual_seed(0)
-for (B, N, M, k, r) in ((32, 64, 1024, 16, 0.1), (32, 1024, 1024, 16, 0.1), (32, 2048, 1024, 16, 0.1), (32, 4096, 1024, 16, 0.1), (32, 4096, 1024, 16, 0.0001), (32, 4096, 1024, 16, 2.0), (32, 8192, 1024, 16, 0.1), (32, 4096, 4096, 16, 0.1)):
+for (B, N, M, k, r) in ((32, 64, 1024, 16, 0.1), (32, 1024, 1024, 16, 0.1), (32, 2048, 1024, 16, 0.1), (32, 4096, 1024, 16, 0.1), (32, 4096, 1024, 16, 0.0001), (32, 4096, 1024, 16, 2.0), (32, 8192, 1024, 16, 0.1), (32, 4096, 4096, 16, 0.1),
+                        (32, 4096, 1024, 32, 0.2), (32, 4096, 1024, 32, 0.0001), (32, 4096, 1024, 128, 0.4), (32, 4096, 1024, 128, 0.0001)):
     pts = torch.rand((B, N, 3), generator=g).cuda()
     q = torch.rand((B, M, 3), generator=g).cuda()
     bi = torch.zeros((B, M, k), dtype=torch.long, device="cuda")

@@ -37,6 +37,7 @@ __device__ __forceinline__ T sq_dist(T qx, T qy, T qz, T sx, T sy, T sz) {
 // Two queries against one support in packed fp32 (v_pk_add_f32 / v_pk_mul_f32: per-element IEEE results identical
 // to the scalar form, half the instructions); the double variant is two scalar evaluations.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned pd_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void sq_dist_pair(float qx0, float qy0, float qz0, float qx1, float qy1, float qz1, float sx,
                                              float sy, float sz, float& d0, float& d1) {
   const f32x2_t dx = f32x2_t{qx0, qx1} - f32x2_t{sx, sx};
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_kernel(const T* __re
 
   T qx[G], qy[G], qz[G];
   int cnt[G], first[G];
+  int nopen = 0;                    // queries of this wave that still take hits
+  __amdgpu_buffer_rsrc_t row[G];    // the output rows of the G queries: k entries each, stores beyond are dropped
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     int qi = q_first + g;
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_kernel(const T* __re
     qy[g] = qp[1];
     qz[g] = qp[2];
     cnt[g] = live ? 0 : k;  // dead slots count as full
-    first[g] = -1;
+    nopen += (live && k > 0) ? 1 : 0;
+    first[g] = INT_MAX;
+    row[g] = __builtin_amdgcn_make_buffer_rsrc(out + ((int64_t)b * M + (live ? qi : 0)) * k, 0, live ? k * 8 : 0, 0x00020000);
   }
 
   for (int t0 = 0; t0 < N; t0 += TS) {
@@ -143,54 +148,65 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_kernel(const T* __re
       for (int i = tcount * 3 + (int)threadIdx.x; i < padded * 3; i += kQueryThreads) tile[i] = static_cast<T>(INFINITY);
     }
     __syncthreads();
-    bool all_full = true;
-#pragma unroll
-    for (int g = 0; g < G; ++g) all_full = all_full && (cnt[g] >= k);
-    if (all_full) continue;  // wave-uniform; keep taking part in the barriers
+    if (nopen == 0) continue;  // wave-uniform; keep taking part in the barriers
     // A full (or dead) query compares against -1 so it can never hit again: the common no-hit chunk is then
     // branch-free (G distance evaluations, G compares, one combined test) and only chunks with a hit pay for slot
     // assignment and stores.
     T lim[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) lim[g] = cnt[g] < k ? r2 : static_cast<T>(-1);
-    for (int c0 = 0; c0 < tcount; c0 += 64) {
-      const int j = c0 + lane;
-      const T sx = tile[j * 3 + 0], sy = tile[j * 3 + 1], sz = tile[j * 3 + 2];  // tail lanes read +inf padding
+    const T* sp = tile + lane * 3;
+    int pos = t0;  // index of the chunk's first support
+    const int pos_end = t0 + tcount;
+    do {
+      const T sx = sp[0], sy = sp[1], sz = sp[2];  // tail lanes read +inf padding
+      sp += 64 * 3;
       unsigned long long m[G];
+      bool hit[G];
       unsigned long long any = 0ull;
 #pragma unroll
       for (int g = 0; g < G; g += 2) {
         T d0, d1;
         sq_dist_pair(qx[g], qy[g], qz[g], qx[g + 1], qy[g + 1], qz[g + 1], sx, sy, sz, d0, d1);
-        m[g] = __ballot(d0 < lim[g]);  // strict, ball_query_cuda.cuh:43
-        m[g + 1] = __ballot(d1 < lim[g + 1]);
+        hit[g] = d0 < lim[g];  // strict, ball_query_cuda.cuh:43
+        hit[g + 1] = d1 < lim[g + 1];
+        m[g] = __ballot(hit[g]);
+        m[g + 1] = __ballot(hit[g + 1]);
         any |= m[g] | m[g + 1];
       }
-      if (any == 0ull) continue;
-      bool open = false;
+      if (any != 0ull) {
+        // The hit path is where this kernel spends a third of its time at the radii of the MSG layers (two of three
+        // chunks hold a hit at r = 0.1, every chunk at r = 0.2 / 0.4), so it is kept to ~20 instructions per query:
+        // the slot is the running count + the hits in the lower lanes (two `v_mbcnt`, the count rides in as the
+        // addend); the store is a buffer store into the query's row of k entries, whose range check drops the slots
+        // >= k, and the lanes without a hit are sent out of range as well; everything else is scalar arithmetic.
+        const int64_t idx = (int64_t)(pos + lane);
+        const pd_u32x2 idx_bits = {(unsigned)idx, (unsigned)(idx >> 32)};
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (m[g]) {  // wave-uniform
-          const bool hit = (m[g] >> lane) & 1ull;
-          const int before = __builtin_popcountll(m[g] & ((1ull << lane) - 1ull));
-          const int slot = cnt[g] + before;
-          if (hit && slot < k) out[((int64_t)b * M + q_first + g) * k + slot] = (int64_t)(t0 + j);
-          if (first[g] < 0) first[g] = t0 + c0 + (__builtin_ffsll((long long)m[g]) - 1);
-          cnt[g] += __builtin_popcountll(m[g]);
-          if (cnt[g] >= k) lim[g] = static_cast<T>(-1);
+        for (int g = 0; g < G; ++g) {
+          if (m[g]) {  // wave-uniform
+            const unsigned slot = __builtin_amdgcn_mbcnt_hi(
+                (unsigned)(m[g] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[g], (unsigned)cnt[g]));
+            __builtin_amdgcn_raw_buffer_store_b64(idx_bits, row[g], hit[g] ? slot * 8u : 0xfffffff8u, 0, 0);
+            first[g] = min(first[g], pos + (int)__builtin_ctzll(m[g]));  // chunks ascend: the minimum is the first hit
+            cnt[g] += __builtin_popcountll(m[g]);
+            const bool full = cnt[g] >= k;  // happens once per query: a full query never hits again
+            lim[g] = full ? static_cast<T>(-1) : lim[g];
+            nopen -= full ? 1 : 0;
+          }
         }
-        open = open || (cnt[g] < k);
+        pos = nopen == 0 ? INT_MAX - 64 : pos;  // every query full: leave (a scalar select, no second loop exit)
       }
-      if (!open) break;
-    }
+      pos += 64;
+    } while (pos < pos_end);
   }
   // A query with 0 < cnt < k repeats its first hit in the remaining slots (ball_query_cuda.cuh:44-48);
   // cnt == 0 leaves the caller's zero fill untouched.
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if (q_first + g < M && cnt[g] > 0 && cnt[g] < k) {
-      int64_t* row = out + ((int64_t)b * M + q_first + g) * k;
-      for (int slot = cnt[g] + lane; slot < k; slot += 64) row[slot] = (int64_t)first[g];
+      int64_t* r = out + ((int64_t)b * M + q_first + g) * k;
+      for (int slot = cnt[g] + lane; slot < k; slot += 64) r[slot] = (int64_t)first[g];
     }
   }
 }
@@ -202,8 +218,8 @@ static int ball_query(const T* q, const T* s, int64_t* out, int B, int M, int N,
   V3D_REQUIRE(B >= 0 && M >= 0 && N >= 0 && k >= 0, what, "negative dimension");
   if (B == 0 || M == 0 || k == 0 || N == 0) return 0;
   V3D_REQUIRE(q && s && out, what, "null pointer");
-  if (B > kMaxGridYZ) {
-    set_last_error("%s: B <= 65535 required", what);
+  if (B > kMaxGridYZ || k > (1 << 27)) {  // a row of k int64 entries is addressed as a buffer of k * 8 bytes
+    set_last_error("%s: B <= 65535 and k <= 2^27 required", what);
     return V3D_ERR_SIZE_LIMIT;
   }
   DeviceGuard guard(device);
