@@ -11,3 +11,12 @@ for (B, N, M, k, r) in ((32, 64, 1024, 16, 0.1), (32, 1024, 1024, 16, 0.1), (32,
     bi = torch.zeros((B, M, k), dtype=torch.long, device="cuda")
     med, mn = timeit(lambda: ext.ball_query(q, pts, bi, r, k))
     print(f"B{B} N{N} M{M} k{k} r{r}: {med*1e3:.1f} us (min {mn*1e3:.1f})")
+# the three MSG scales of config 2: one multi-scale launch against three single-scale launches
+from vision3d_amd import ops
+pts = torch.rand((32, 4096, 3), generator=g).cuda()
+q = pts[:, :1024].contiguous()
+ks, rs = (16, 32, 128), (0.1, 0.2, 0.4)
+med, mn = timeit(lambda: ops.ball_query_multi(q, pts, ks, rs))
+print(f"ball_query_multi C2: {med*1e3:.1f} us (min {mn*1e3:.1f})")
+med, mn = timeit(lambda: [ops.ball_query(q, pts, k, r) for k, r in zip(ks, rs)])
+print(f"three ball_query C2: {med*1e3:.1f} us (min {mn*1e3:.1f})")

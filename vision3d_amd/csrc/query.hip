@@ -258,6 +258,7 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_multi_kernel(const f
   float qx[G], qy[G], qz[G];
   int cnt[G][S], first[G][S];
   float lim[G][S];
+  int nopen = 0;  // (query, scale) lists of this wave that still take hits
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int qi = q_first + g;
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_multi_kernel(const f
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       cnt[g][i] = live ? 0 : sc.k[i];  // dead slots count as full
-      first[g][i] = -1;
+      nopen += (live && sc.k[i] > 0) ? 1 : 0;
+      first[g][i] = INT_MAX;
     }
   }
 
@@ -282,20 +284,20 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_multi_kernel(const f
       for (int i = tcount * 3 + (int)threadIdx.x; i < padded * 3; i += kQueryThreads) tile[i] = INFINITY;
     }
     __syncthreads();
-    bool all_full = true;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
-      for (int i = 0; i < S; ++i) {
-        all_full = all_full && (cnt[g][i] >= sc.k[i]);
-        lim[g][i] = cnt[g][i] < sc.k[i] ? sc.r2[i] : -1.0f;  // a full (or dead) list can never hit again
-      }
+      for (int i = 0; i < S; ++i) lim[g][i] = cnt[g][i] < sc.k[i] ? sc.r2[i] : -1.0f;  // a full (or dead) list never hits
     }
-    if (all_full) continue;  // wave-uniform; keep taking part in the barriers
-    for (int c0 = 0; c0 < tcount; c0 += 64) {
-      const int j = c0 + lane;
-      const float sx = tile[j * 3 + 0], sy = tile[j * 3 + 1], sz = tile[j * 3 + 2];
+    if (nopen == 0) continue;  // wave-uniform; keep taking part in the barriers
+    const float* sp = tile + lane * 3;
+    int pos = t0;  // index of the chunk's first support
+    const int pos_end = t0 + tcount;
+    do {
+      const float sx = sp[0], sy = sp[1], sz = sp[2];
+      sp += 64 * 3;
       unsigned long long m[G][S];
+      bool hit[G][S];
       unsigned long long any = 0ull;
 #pragma unroll
       for (int g = 0; g < G; g += 2) {
@@ -303,31 +305,36 @@ __global__ __launch_bounds__(kQueryThreads) void ball_query_multi_kernel(const f
         sq_dist_pair(qx[g], qy[g], qz[g], qx[g + 1], qy[g + 1], qz[g + 1], sx, sy, sz, d0, d1);
 #pragma unroll
         for (int i = 0; i < S; ++i) {
-          m[g][i] = __ballot(d0 < lim[g][i]);  // strict, ball_query_cuda.cuh:43
-          m[g + 1][i] = __ballot(d1 < lim[g + 1][i]);
+          hit[g][i] = d0 < lim[g][i];  // strict, ball_query_cuda.cuh:43
+          hit[g + 1][i] = d1 < lim[g + 1][i];
+          m[g][i] = __ballot(hit[g][i]);
+          m[g + 1][i] = __ballot(hit[g + 1][i]);
           any |= m[g][i] | m[g + 1][i];
         }
       }
-      if (any == 0ull) continue;
-      bool open = false;
+      if (any != 0ull) {  // the hit path of ball_query_kernel, per (query, scale) list
+        const int64_t idx = (int64_t)(pos + lane);
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int i = 0; i < S; ++i) {
-          const unsigned long long mm = m[g][i];
-          if (mm) {  // wave-uniform
-            const bool hit = (mm >> lane) & 1ull;
-            const int slot = cnt[g][i] + __builtin_popcountll(mm & ((1ull << lane) - 1ull));
-            if (hit && slot < sc.k[i]) sc.out[i][((int64_t)b * M + q_first + g) * sc.k[i] + slot] = (int64_t)(t0 + j);
-            if (first[g][i] < 0) first[g][i] = t0 + c0 + (__builtin_ffsll((long long)mm) - 1);
-            cnt[g][i] += __builtin_popcountll(mm);
-            if (cnt[g][i] >= sc.k[i]) lim[g][i] = -1.0f;
+          for (int i = 0; i < S; ++i) {
+            const unsigned long long mm = m[g][i];
+            if (mm) {  // wave-uniform
+              const unsigned slot = __builtin_amdgcn_mbcnt_hi(
+                  (unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, (unsigned)cnt[g][i]));
+              if (hit[g][i] && slot < (unsigned)sc.k[i]) sc.out[i][((int64_t)b * M + q_first + g) * sc.k[i] + slot] = idx;
+              first[g][i] = min(first[g][i], pos + (int)__builtin_ctzll(mm));  // chunks ascend: the minimum is the first hit
+              cnt[g][i] += __builtin_popcountll(mm);
+              const bool full = cnt[g][i] >= sc.k[i];  // happens once per list: a full list never hits again
+              lim[g][i] = full ? -1.0f : lim[g][i];
+              nopen -= full ? 1 : 0;
+            }
           }
-          open = open || (cnt[g][i] < sc.k[i]);
         }
+        pos = nopen == 0 ? INT_MAX - 64 : pos;  // every list full: leave (a scalar select, no second loop exit)
       }
-      if (!open) break;
-    }
+      pos += 64;
+    } while (pos < pos_end);
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
