@@ -454,7 +454,8 @@ constexpr int kTopkAhead = 8;   // 64-column groups requested together on the in
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ D, int64_t rows, int ncols,
                                                         int64_t ld, int col_base, int k, int first_chunk,
                                                         float* __restrict__ run_d, int* __restrict__ run_i) {
-  __shared__ float2 cand_s[4][kTopkCand];
+  // candidates as (distance bits << 32 | column) words; + 4: the ranking's halves read up to three sentinels past the end
+  __shared__ __align__(16) unsigned long long cand_s[4][kTopkCand + 4];
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -489,21 +490,24 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = (t << 10) + ((u << 6) + lane) * 4;
-        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lmin = fminf(lmin, c + q < ncols ? e[q] : INFINITY);
-        keep[u] = v[u];  // (the last tile's; used only when it is the only one)
+        for (int q = 0; q < 4; ++q) {
+          e[q] = c + q < ncols ? e[q] : INFINITY;  // columns past the end never qualify, here or below
+          lmin = fminf(lmin, e[q]);
+        }
+        keep[u] = make_float4(e[0], e[1], e[2], e[3]);  // (the last tile's; used only when it is the only one)
       }
     }
     // k-th smallest of the 64 minima (distances are >= 0, so the IEEE pattern orders like an integer): bit-wise binary
     // search, one compare + ballot + popcount per bit
     const unsigned lbits = __float_as_uint(lmin);
     unsigned prefix = 0;
-    for (int bit = 30; bit >= 7; --bit) {  // the low 7 bits are not searched: all ones keeps it an upper bound, 2^-17 looser
-      const unsigned trial = prefix | (1u << bit);
+    for (int bit = 30; bit >= 15; --bit) {  // the low 15 bits are not searched: all ones keeps it an upper bound, at most
+      const unsigned trial = prefix | (1u << bit);  // 2^-9 looser (about one more candidate per row at config 3)
       if (__builtin_popcountll(__ballot(lbits < trial)) <= k - 1) prefix = trial;
     }
-    prefix |= 0x7fu;
+    prefix |= 0x7fffu;
     const float kth = __uint_as_float(prefix);
     // strict '<' below must still admit values equal to the bound: step to the next float (kth >= 0)
     cap = kth < INFINITY ? __uint_as_float(__float_as_uint(kth) + 1u) : INFINITY;
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   // in LDS and ranked against each other in one go -- every lane ranks one candidate by (distance, column) -- instead
   // of one whole-wave shift per candidate.  More than kTopkCand candidates: the insertion path below takes the row.
   if (first_chunk && cap < INFINITY) {
-    float2* cand = cand_s[threadIdx.x >> 6];
+    unsigned long long* cand = cand_s[threadIdx.x >> 6];
     int count = 0;
     for (int t = 0; t < ntile && count <= kTopkCand; ++t) {
       float4 v[4];
@@ -524,32 +528,57 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
         for (int u = 0; u < 4; ++u) {
           const int c = (t << 10) + ((u << 6) + lane) * 4;
           v[u] = *reinterpret_cast<const float4*>(drow + (c < ncols ? c : 0));
+          if (c + 3 >= ncols) {  // the row's last columns (rows are padded to 128 columns, not to a tile)
+            v[u].x = c < ncols ? v[u].x : INFINITY;
+            v[u].y = c + 1 < ncols ? v[u].y : INFINITY;
+            v[u].z = c + 2 < ncols ? v[u].z : INFINITY;
+            v[u].w = c + 3 < ncols ? v[u].w : INFINITY;
+          }
         }
       }
+      // The selection is bound by instruction issue, and this loop was half of it (26 instructions per element as
+      // compiled from compare / mask / popcount / conditional store): a hit's slot is the running count + the hits in
+      // the lower lanes (two `v_mbcnt`, the count rides in as the addend), clamped to the spare slot behind the list.
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = (t << 10) + ((u << 6) + lane) * 4;
         const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const bool in = c + q < ncols && e[q] < cap;
+          const bool in = e[q] < cap;
           const unsigned long long m = __ballot(in);
-          const int slot = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-          // (column, distance) so that the pair read as one 64-bit word orders by (distance, column); -0 becomes +0
-          if (in && slot < kTopkCand) cand[slot] = make_float2(__int_as_float(col_base + c + q), e[q] == 0.f ? 0.f : e[q]);
+          const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)count));
+          // (distance, column) as one 64-bit word that orders by (distance, column); e + 0 turns -0 into +0
+          if (in)
+            cand[min(slot, (unsigned)kTopkCand)] =
+                ((unsigned long long)__float_as_uint(e[q] + 0.0f) << 32) | (unsigned)(col_base + c + q);
           count += __builtin_popcountll(m);
         }
       }
     }
     if (count <= kTopkCand) {  // count >= k: the bound is attained by k distinct columns
+      // Every candidate's rank = the candidates below it (distances are >= +0: the bit pattern orders like the value;
+      // columns differ, so the order is strict).  32 candidates per pass: lanes l and l + 32 hold the same candidate and
+      // count over one half of the list each (a wave-wide pass left half of the lanes idle at the ~30 candidates a row
+      // has), two words per LDS read; the halves may run past the end into sentinels.
+      if (lane < 4) cand[count + lane] = ~0ull;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int j0 = 0; j0 < count; j0 += 64) {
-        const int j = j0 + lane;
-        const unsigned long long* cand64 = reinterpret_cast<const unsigned long long*>(cand);
-        const unsigned long long me = cand64[j < count ? j : 0];  // distances are >= +0: the bit pattern orders like the value
+      const int half = lane >> 5;
+      const int mid = ((count + 3) >> 2) << 1;  // even (16-byte reads), 2 * mid >= count
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      const u64x2* part = reinterpret_cast<const u64x2*>(cand + half * mid);
+      for (int j0 = 0; j0 < count; j0 += 32) {
+        const int j = j0 + (lane & 31);
+        const unsigned long long me = cand[j < count ? j : 0];
         int rank = 0;
-        for (int i = 0; i < count; ++i) rank += cand64[i] < me ? 1 : 0;  // same address in every lane: LDS broadcast
-        if (j < count && rank < k) {
+        for (int i = 0; i < (mid >> 1); ++i) {
+          const u64x2 two = part[i];
+          rank += two.x < me ? 1 : 0;
+          rank += two.y < me ? 1 : 0;
+        }
+        rank += __shfl_xor(rank, 32, 64);
+        if (half == 0 && j < count && rank < k) {
           run_d[row * k + rank] = __uint_as_float((unsigned)(me >> 32));
           run_i[row * k + rank] = (int)(unsigned)me;
         }
@@ -721,15 +750,37 @@ __global__ __launch_bounds__(256) void knn_feat_finalize_kernel(const float* __r
     }
   }
   // rank sort among the k entries (k <= 64): position = number of entries that precede mine.  (distance, index) as one
-  // 64-bit key -- distances are sqrt results, >= +0, so the bit pattern orders like the value; unfilled entries carry the
-  // largest key -- makes "precedes" a single compare per entry.
+  // 64-bit key -- distances are sqrt results, >= +0, so the bit pattern orders like the value; unfilled entries and the
+  // lanes >= k carry the largest key -- makes "precedes" a single compare per entry.  The keys go through LDS: 32 entries
+  // per pass, lanes l and l + 32 hold the same entry and count over one half of the list each, two keys per read (a
+  // `v_readlane` pair per key and a wave-wide pass, half of its lanes idle at k = 25, were a third of this kernel).
+  __shared__ __align__(16) unsigned long long keys_s[4][64];
+  unsigned long long* keys = keys_s[threadIdx.x >> 6];
   const unsigned long long key =
       idx < 0 ? ~0ull : (((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(unsigned)idx);
+  keys[lane] = key;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int rank = 0;
-  for (int j = 0; j < k; ++j) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, j);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), j);
-    rank += ((((unsigned long long)hi) << 32) | lo) < key ? 1 : 0;
+  {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int half = lane >> 5;
+    const int mid = ((k + 3) >> 2) << 1;  // even (16-byte reads), k <= 2 * mid <= 64: past k the keys are the largest
+    const u64x2* part = reinterpret_cast<const u64x2*>(keys + half * mid);
+    int mine_rank = 0;
+    for (int j0 = 0; j0 < k; j0 += 32) {
+      const unsigned long long me = keys[j0 + (lane & 31)];
+      int r = 0;
+      for (int i = 0; i < (mid >> 1); ++i) {
+        const u64x2 two = part[i];
+        r += two.x < me ? 1 : 0;
+        r += two.y < me ? 1 : 0;
+      }
+      r += __shfl_xor(r, 32, 64);
+      // entry j0 + (lane & 31) is lane `that`'s: hand the rank to its owner (a no-op move for the first pass)
+      const int got = __shfl(r, lane & 31, 64);
+      if ((lane >> 5) == (j0 >> 5)) mine_rank = got;
+    }
+    rank = mine_rank;
   }
   if (lane < k) {
     // unfilled entries (M < k) all tie: keep them behind the real ones in lane order
