@@ -23,7 +23,29 @@ def table(rng, m, k, n):
 
 
 def one_case(rng, i):
-    kind = i % 17
+    kind = i % 19
+    if kind == 17:  # single-scale ball query (the (a) row): both dtypes, lattices (pairs exactly at the radius), every k class
+        dt = np.float32 if rng.integers(4) else np.float64
+        b, m, n = int(rng.integers(1, 4)), int(rng.integers(1, 600)), int(rng.integers(1, 5000))
+        sup = rng.random((b, n, 3)).astype(dt)
+        if rng.integers(2):
+            sup = (np.round(sup * 5) / 5).astype(dt)
+        qs = (sup[:, rng.integers(0, n, size=m)] + (rng.random((b, m, 3)) < 0.1) * 3.0).astype(dt)
+        k = int(rng.choice([1, 3, 16, 32, 63, 64, 65, 128, 200]))
+        r = float(rng.choice([0.0, 0.01, 0.1, 0.2, 0.4, 2.0]))
+        out = torch.zeros((b, m, k), dtype=torch.long, device=DEV)
+        ext.ball_query(T(qs), T(sup), out, r, k)
+        return np.array_equal(N_(out), oracle.ball_query(qs, sup, k, r)), f"ball_query {dt.__name__} b{b} m{m} n{n} k{k} r{r}"
+    if kind == 18:  # furthest point sampling: sizes around the geometry switches, duplicate-heavy clouds (ties)
+        b = int(rng.integers(1, 4))
+        n = int(rng.choice([1, 2, 63, 64, 65, 500, 1024, 1025, 2048, 4096, 4097, 8192, 9000, 17000]))
+        m = int(rng.integers(1, min(n, 300) + 1))
+        pts = rng.random((b, n, 3), dtype=np.float32)
+        if rng.integers(3) == 0:
+            pts = (np.round(pts * 4) / 4).astype(np.float32)
+        want = oracle.furthest_point_sample(pts, m)
+        got = ops.furthest_point_sample(T(pts), m, gather_points=False)
+        return np.array_equal(N_(got), want), f"fps b{b} n{n} m{m}"
     if kind == 16:  # pairwise distance: the tile sweep (whole tiles, shifted edge tiles), the one-tile kernels, every flag
         b = int(rng.integers(1, 4))
         n, m = int(rng.integers(1, 700)), int(rng.integers(1, 700))
