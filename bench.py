@@ -163,6 +163,79 @@ class Step:
                     lambda: ext.three_interpolate_backward(inp["grad"], self.tnn_i, w, self.sgrad, M))
 
 
+class PipelinedStep:
+    """The same operator sequence on the same inputs for ONE batch, the sampling cut into `pieces` launches
+    (ext.furthest_point_sample_rounds): the ball queries and gathers of the first centroids run on a second
+    stream while the sampling -- a serial chain on B of the 256 CUs -- goes on.  Outputs per piece; three_nn and the
+    interpolation need all centroids and follow the last piece.  Few, larger launches (one ball_query_multi per piece,
+    one zero fill per scale): issued from Python a launch costs ~10 us of host time, and a HIP graph of the two-stream
+    schedule replays slower than the plain launches (tools/pipe_probe.py).  Not the reference's call pattern (one launch
+    samples all M): reported beside the headline as `ms_per_step_single_batch_pipelined`, never as `value`."""
+
+    def __init__(self, inp, device, cuts=(0, M // 2, M)):
+        import torch
+
+        from vision3d_amd import ext
+
+        # the consumers of a piece run under the sampling of the pieces after it; what follows the last piece is exposed.
+        # Two halves measured best (tools/pipe_probe.py: 0.85 ms against 0.92 for 512 + 256 + 256 and 0.91 for four
+        # quarters): every piece pays ~0.1 ms in launches that are too small to fill the chip
+        assert cuts[0] == 0 and cuts[-1] == M and all(a < b and a % 64 == 0 for a, b in zip(cuts[:-1], cuts[1:]))
+        self.torch, self.ext, self.inp, self.cuts = torch, ext, inp, tuple(cuts)
+        self.pieces = len(cuts) - 1
+        dev = device
+        self.pts = inp["pts"]
+        self.pts_cf = self.pts.transpose(1, 2).contiguous()
+        self.fps_dist = torch.empty((B, N), device=dev)
+        self.fps_idx = torch.zeros((B, M), dtype=torch.long, device=dev)
+        # one flat index buffer per scale (one zero fill), carved into the pieces' (B, m_piece, k) tensors
+        self.ball_flat = [torch.zeros((B * M * k,), dtype=torch.long, device=dev) for _, k in SCALES]
+        self.ball_idx = [[f[B * a * k:B * b * k].view(B, b - a, k) for a, b in zip(cuts[:-1], cuts[1:])]
+                         for f, (_, k) in zip(self.ball_flat, SCALES)]
+        self.g_xyz = [[torch.empty((B, 3, b - a, k), device=dev) for _, k in SCALES] for a, b in zip(cuts[:-1], cuts[1:])]
+        self.g_feat = [[torch.empty((B, C_FEAT, b - a, k), device=dev) for _, k in SCALES]
+                       for a, b in zip(cuts[:-1], cuts[1:])]
+        self.tnn_d = torch.empty((B, N, 3), device=dev)
+        self.tnn_i = torch.zeros((B, N, 3), dtype=torch.long, device=dev)
+        self.interp = torch.empty((B, C_INTERP, N), device=dev)
+        self.sgrad = torch.empty((B, C_INTERP, M), device=dev)
+        self.side = torch.cuda.Stream(device=dev)
+        self.start = torch.cuda.Event()
+        self.sampled = [torch.cuda.Event() for _ in range(self.pieces)]
+        self.grouped = torch.cuda.Event()
+        self.radii, self.ks = [r for r, _ in SCALES], [k for _, k in SCALES]
+
+    def run(self):
+        torch, ext, inp, cuts = self.torch, self.ext, self.inp, self.cuts
+        main = torch.cuda.current_stream()
+        self.start.record(main)
+        self.fps_dist.fill_(1e10)
+        for p in range(self.pieces):
+            ext.furthest_point_sample_rounds(self.pts, self.fps_dist, self.fps_idx, M, cuts[p], cuts[p + 1])
+            self.sampled[p].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.start)
+            for t in self.ball_flat:
+                t.zero_()
+            for p in range(self.pieces):
+                self.side.wait_event(self.sampled[p])
+                idx = self.fps_idx[:, cuts[p]:cuts[p + 1]]
+                q = torch.gather(self.pts, 1, idx.unsqueeze(-1).expand(-1, -1, 3))  # (B, m_piece, 3) centroids
+                ext.ball_query_multi(q, self.pts, [t[p] for t in self.ball_idx], self.radii, self.ks)
+                for i in range(len(SCALES)):
+                    ext.group_gather_forward(self.pts_cf, self.ball_idx[i][p], self.g_xyz[p][i])
+                    ext.group_gather_forward(inp["feats"], self.ball_idx[i][p], self.g_feat[p][i])
+            self.grouped.record(self.side)
+        # feature propagation needs every centroid: after the last piece, on the main stream (beside the last grouping)
+        q_all = torch.gather(self.pts, 1, self.fps_idx.unsqueeze(-1).expand(-1, -1, 3))
+        ext.three_nn(self.pts, q_all, self.tnn_d, self.tnn_i)
+        w = 1.0 / (self.tnn_d + 1e-5)
+        w = w / w.sum(dim=2, keepdim=True)
+        ext.three_interpolate_forward(inp["sfeats"], self.tnn_i, w, self.interp)
+        ext.three_interpolate_backward(inp["grad"], self.tnn_i, w, self.sgrad, M)
+        main.wait_event(self.grouped)
+
+
 def algorithmic_bytes():
     """SURVEY.md 8(d) formulas, per launch."""
     out = {}
@@ -527,6 +600,23 @@ def rank_main(args):
     bracket()
     elapsed_single = max_over_ranks(time.perf_counter() - t1)
 
+    # ... and one batch in flight with the sampling cut into four launches, its consumers overlapped (PipelinedStep)
+    elapsed_pipe = None
+    if world == 1:
+        pstep = PipelinedStep(inp, device)
+        for _ in range(min(args.warmup, 3)):
+            pstep.run()
+        bracket()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pstep.run()
+        bracket()
+        elapsed_pipe = time.perf_counter() - t1
+        pipe_equal = bool(torch.equal(pstep.fps_idx, steps[0].fps_idx) and torch.equal(pstep.sgrad, steps[0].sgrad)
+                          and all(torch.equal(torch.cat([pstep.g_feat[p][i] for p in range(pstep.pieces)], dim=2),
+                                              steps[0].g_feat[i]) for i in range(len(SCALES))))
+        del pstep
+
     c5 = None
     if dist is not None and not args.no_per_config:
         job = C5Sharded(torch, dist, device, world, rank, k=3)
@@ -567,6 +657,12 @@ def rank_main(args):
             "ms_per_step": ms_per_step,
             "ms_per_step_single_stream": elapsed_single / args.steps * 1e3,
             "value_single_stream": QUERIES_PER_STEP * args.steps * world / elapsed_single,
+            "ms_per_step_single_batch_pipelined": None if elapsed_pipe is None else elapsed_pipe / args.steps * 1e3,
+            "single_batch_pipelined": None if elapsed_pipe is None else {
+                "what": "one batch in flight, FPS in 2 launches (v3d_fps_resume_f32: rounds 0-511, 512-1023), ball queries / "
+                        "gathers of the first half on a second stream under the sampling of the second; not the "
+                        "reference's call pattern",
+                "equals_plain_step": pipe_equal},
             "scaling": "weak",
             "config": {"workload": "pointnet2_msg_fp_s3dis", "B_per_gpu": B, "N": N, "M": M,
                        "scales": [list(s) for s in SCALES], "C_group": C_FEAT, "C_interp": C_INTERP,

@@ -54,6 +54,14 @@ int v3d_device_count(int* count);            /* hipGetDeviceCount wrapper used b
 int v3d_fps_ref_block(int num_points);       /* opt_n_threads, furthest_point_sample_cuda.cuh:9-12 */
 int v3d_fps_f32(const float* points, float* distances, int64_t* indices, int B, int N, int M, int device,
                 void* stream);
+/* The same sampling in pieces: rounds [first, last) of a run of M samples per cloud, indices (B,M).  The rounds
+ * [0, first) were written into indices[:, :first] by earlier calls, which left the running min-distances in
+ * `distances`; first % 64 == 0, last <= M.  Calls with (first, last) = (0, m1), (m1, m2), ..., (mj, M) produce exactly
+ * what v3d_fps_f32 produces.  No counterpart in the reference (its kernel always runs all M rounds,
+ * furthest_point_sample_cuda.cuh:54): it is for callers that start the consumers of the first samples (ball query,
+ * grouping) while the sampling goes on -- the sampling is a serial chain on B of the 256 CUs. */
+int v3d_fps_resume_f32(const float* points, float* distances, int64_t* indices, int B, int N, int M, int first,
+                       int last, int device, void* stream);
 
 /* ---- ball query -------------------------------------------------------------------------------------
  * replaces vision3d::ball_query (csrc/cuda/ball_query/ball_query.h:7-12; kernel ball_query_cuda.cuh:11-55).

@@ -101,6 +101,43 @@ def test_fps_more_samples_than_points_and_scratch_state(ext, oracle_mod):
     assert torch.all(dist == 0)  # every point was selected: the in/out scratch holds the final min-distances
 
 
+@pytest.mark.parametrize("n", [100, 700, 1024, 3000, 4096, 8192, 12000, 20000])
+def test_fps_in_pieces_equals_one_call(ext, oracle_mod, n):
+    """`first` / `last` (v3d_fps_resume_f32): the rounds of one sampling spread over several launches -- every kernel
+    geometry (split block, table, winner re-read, streaming), random and tie-heavy clouds -- give the indices and the
+    final running distances of the single launch, which equal the oracle's."""
+    rng = np.random.default_rng(n)
+    m = min(n, 330)
+    for lattice in (False, True):
+        pts = rng.random((2, n, 3), dtype=np.float32)
+        if lattice:
+            pts = (np.round(pts * 5) / 5).astype(np.float32)
+        want = oracle_mod.furthest_point_sample(pts, m)
+        one_d = torch.full((2, n), 1e10, dtype=torch.float32, device=DEV)
+        one_i = torch.zeros((2, m), dtype=torch.long, device=DEV)
+        ext.furthest_point_sample(T(pts), one_d, one_i, m)
+        assert np.array_equal(N_(one_i), want)
+        dist = torch.full((2, n), 1e10, dtype=torch.float32, device=DEV)
+        idx = torch.full((2, m), -7, dtype=torch.long, device=DEV)
+        cuts = [c for c in (0, 64, 256, 320) if c < m] + [m]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ext.furthest_point_sample_rounds(T(pts), dist, idx, m, a, b)
+            assert torch.all(idx[:, b:] == -7)  # nothing beyond the piece is written
+        assert torch.equal(idx, one_i), (n, lattice)
+        assert torch.equal(dist, one_d), (n, lattice)
+
+
+def test_fps_in_pieces_argument_checks(ext):
+    pts = torch.rand((1, 200, 3), device=DEV)
+    dist = torch.full((1, 200), 1e10, device=DEV)
+    idx = torch.zeros((1, 128), dtype=torch.long, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ext.furthest_point_sample_rounds(pts, dist, idx, 128, 32, 128)
+    with pytest.raises(RuntimeError, match="beyond"):
+        ext.furthest_point_sample_rounds(pts, dist, idx, 128, 64, 129)
+    ext.furthest_point_sample_rounds(pts, dist, idx, 128, 128, 128)  # nothing left to do: not an error
+
+
 def test_fps_full_config_sizes(ext, oracle_mod):
     """BASELINE configs C1 (B=16, N=1024 -> 512) and C2 (B=32, N=4096 -> 1024), full size, bit-exact."""
     rng = np.random.default_rng(0)

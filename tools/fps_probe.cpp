@@ -40,7 +40,7 @@ static float launch(const float* pts, float* dist, int64_t* idx, int B, int N, i
   hipEventCreate(&b);
   hipEventRecord(a);
   hipLaunchKernelGGL((v3d::fps_kernel<T, P, MODE, PROBE, J>), dim3(B), dim3(T), MODE == v3d::kFpsTable ? (size_t)T * P * 16 : 0, 0,
-                     pts, dist, idx, N, M, lb);
+                     pts, dist, idx, N, M, lb, 0, M);
   hipEventRecord(b);
   hipEventSynchronize(b);
   float ms;

@@ -27,6 +27,7 @@ SIGNATURES = {
     "v3d_device_count": (_c_int, [ctypes.POINTER(_c_int)]),
     "v3d_fps_ref_block": (_c_int, [_c_int]),
     "v3d_fps_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int] + _TAIL),
+    "v3d_fps_resume_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_ball_query_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32, _c_int] + _TAIL),
     "v3d_ball_query_f64": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32, _c_int] + _TAIL),
     "v3d_ball_query_multi_f32": (

@@ -28,10 +28,18 @@ int v3d_fps_ref_block(int num_points) {
 
 int v3d_fps_f32(const float* points, float* distances, int64_t* indices, int B, int N, int M, int device,
                 void* stream_) {
+  return v3d_fps_resume_f32(points, distances, indices, B, N, M, 0, M, device, stream_);
+}
+
+int v3d_fps_resume_f32(const float* points, float* distances, int64_t* indices, int B, int N, int M_total, int first,
+                       int last, int device, void* stream_) {
   using namespace v3d;
   const char* what = "furthest_point_sample";
-  V3D_REQUIRE(B >= 0 && N >= 0 && M >= 0, what, "negative dimension");
-  if (B == 0 || M == 0) return 0;
+  V3D_REQUIRE(B >= 0 && N >= 0 && M_total >= 0, what, "negative dimension");
+  V3D_REQUIRE(first >= 0 && first % 64 == 0, what, "a resumed sampling starts at a multiple of 64 rounds");
+  V3D_REQUIRE(last <= M_total, what, "rounds beyond the row of samples");
+  const int M = last;  // this launch: rounds [first, last) of rows of M_total samples
+  if (B == 0 || M <= 0 || first >= M) return 0;
   V3D_REQUIRE(N > 0, what, "cannot sample from an empty cloud");
   V3D_REQUIRE(points && distances && indices, what, "null pointer");
   if ((int64_t)N * 3 > (int64_t)INT32_MAX) {
@@ -46,7 +54,7 @@ int v3d_fps_f32(const float* points, float* distances, int64_t* indices, int B, 
 #define V3D_FPS_J(T_, P_, M_, J_)                                                                          \
   hipLaunchKernelGGL((fps_kernel<T_, P_, M_, FpsNoProbe, J_>), dim3(B), dim3(T_),                          \
                      (M_) == kFpsTable ? (size_t)(T_) * (P_) * sizeof(float4) : 0, stream, points, distances, \
-                     indices, N, M, lb)
+                     indices, N, M, lb, first, M_total)
 #define V3D_FPS(T_, P_, M_) V3D_FPS_J(T_, P_, M_, 0)
   // THREADS is a multiple of the reference block `bs`, or bs / 2^J (see fps_kernel.h): bs <= 512 is a power of two.
   // Geometries from tools/fps_probe.cpp: a round costs about (instructions issued per SIMD) x 5 cycles, so small clouds

@@ -175,7 +175,8 @@ __host__ __device__ constexpr int fps_slot_k(int i) {
 
 template <int THREADS, int PPT, int MODE, class PROBE = FpsNoProbe, int LOG_SPLIT = 0>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float* __restrict__ pts, float* __restrict__ dist_io,
-                                                      int64_t* __restrict__ out_idx, int N, int M, int lb) {
+                                                      int64_t* __restrict__ out_idx, int N, int M, int lb,
+                                                      int first, int ld) {
   constexpr int W = THREADS / 64;
   constexpr bool STREAM = MODE == kFpsStream;
   static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16, "waves per workgroup");
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float* __restrict__ 
   const int b = blockIdx.x;
   pts += (int64_t)b * N * 3;
   dist_io += (int64_t)b * N;
-  out_idx += (int64_t)b * M;
+  out_idx += (int64_t)b * ld;  // rounds [first, M) of a row of ld samples
 
   // priority of this thread's slot i (see the header comment): LOG_SPLIT == 0: prio_base + i * prio_step;
   // LOG_SPLIT == j: prio_base + ((i / Q) << kPrioShift) + (i % Q), Q = PPT >> j (tid < block / 2^j, so tid >> lb == 0)
@@ -220,7 +221,10 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float* __restrict__ 
     }
   }
   if (MODE == kFpsTable) __syncthreads();
-  float x1 = pts[0], y1 = pts[1], z1 = pts[2];  // old = 0  (:50,:57-59)
+  // old = 0 (:50,:57-59) -- or, resuming at round `first` (a multiple of 64; the running min-distances arrive in
+  // dist_io as the previous launch left them), the sample of round first - 1
+  const int old = first > 0 ? (int)out_idx[first - 1] : 0;
+  float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
   int hist = 0;  // wave 0: lane j <-> the winner's priority of round (chunk * 64 + j); round 0 = priority 0 = point 0 (:51)
 
   PROBE probe;
@@ -347,7 +351,12 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float* __restrict__ 
     }
     probe.mark(6);
   };
-  for (int s = 1; s < M; s += 2) {
+  int s = 1;
+  if (first > 0) {  // even: its round uses the parity-0 slots, then the pairs go on as below
+    round(std::integral_constant<int, 0>(), first);
+    s = first + 1;
+  }
+  for (; s < M; s += 2) {
     round(std::integral_constant<int, 1>(), s);
     if (s + 1 < M) round(std::integral_constant<int, 0>(), s + 1);
   }

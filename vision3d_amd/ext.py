@@ -17,6 +17,7 @@ __all__ = [
     "ball_query",
     "ball_query_multi",
     "furthest_point_sample",
+    "furthest_point_sample_rounds",
     "gather_forward",
     "gather_backward",
     "group_gather_forward",
@@ -151,6 +152,13 @@ def ball_query(q_points, s_points, indices, max_radius, num_samples):
 
 
 def furthest_point_sample(points, distances, indices, num_samples):
+    furthest_point_sample_rounds(points, distances, indices, num_samples, 0, num_samples)
+
+
+def furthest_point_sample_rounds(points, distances, indices, num_samples, first, last):
+    """Not in the reference's extension: only the rounds [first, last) of the sampling of ``num_samples`` points, the
+    rounds before them already in ``indices[:, :first]`` and the running distances in ``distances`` (first % 64 == 0).
+    For callers that start the consumers of the first samples while the sampling goes on (v3d_fps_resume_f32)."""
     _check_cuda_contiguous(points, "points")
     _check_cuda_contiguous(distances, "distances")
     _check_cuda_contiguous(indices, "indices")
@@ -159,8 +167,9 @@ def furthest_point_sample(points, distances, indices, num_samples):
     _check_long(indices, "indices")
     B, N = points.size(0), points.size(1)
     dev, stream = _where(points)
-    _lib.check(_lib.lib().v3d_fps_f32(points.data_ptr(), distances.data_ptr(), indices.data_ptr(), B, N,
-                                      int(num_samples), dev, stream), "furthest_point_sample")
+    _lib.check(_lib.lib().v3d_fps_resume_f32(points.data_ptr(), distances.data_ptr(), indices.data_ptr(), B, N,
+                                             int(num_samples), int(first), int(last), dev, stream),
+               "furthest_point_sample")
 
 
 def _gather_forward(name, kernel, sources, indices, targets, grouped):
