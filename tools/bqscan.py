@@ -1,3 +1,5 @@
+"""(GPU box) ball_query time against support count and radius: a radius of 1e-4 never hits (the bare scan), 2.0 fills at
+once; then the three MSG scales of config 2 in one multi-scale launch against three single-scale launches."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from vision3d_amd import ext
