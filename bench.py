@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path of BASELINE.json config[1] on N GPUs of one node, plus one short line per other config.
 
-usage: python bench.py --gpus N --steps K --warmup W [--workload c2|c5_refset]
+usage: python bench.py --gpus N --steps K --warmup W [--workload c2|c5_refset|c4_pyramid]
   Under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set, e.g. torch.distributed.run) this process IS one rank.  Without
   one and with --gpus N > 1 this process is only a parent: it starts N rank processes itself (before anything touches
   the GPU), relays rank 0's JSON line and exits with the worst child code.
@@ -27,7 +27,10 @@ vision3d/array_ops/{ball_query,knn}.py call it) on the same inputs.
 `per_config` (after the timed region, excluded from ms_per_step) carries the other BASELINE configs: C1 step, C3 feature
 kNN, C4 radius search + grid subsampling, C5 one-GPU shard, and -- when N > 1 -- C5 with the reference set sharded over
 the ranks: partial top-k per rank, ONE all-gather over RCCL, merge, compared on the device with the single-GPU result.
-`--workload c5_refset` makes that sharded search the timed step (scaling "strong": 100k queries in total).
+`--workload c5_refset` makes that sharded search the timed step (scaling "strong": 100k queries in total).  When N > 1
+`per_config` also carries C4 under pack-mode batch sharding (`c4_kpconv_pyramid_sharded`: 16 clouds of 30,000 points per
+rank split by `lengths`, the 4-stage grid + radius pyramid per rank, no collective, checked against the single-process
+tables); `--workload c4_pyramid` makes that the timed step (scaling "weak").
 """
 import argparse
 import json
@@ -418,6 +421,11 @@ def per_config_single(torch, device):
                                       "radius_search_ms": ms_r, "radius_queries_per_sec": nc * n4 / (ms_r * 1e-3),
                                       "grid_subsample_ms": ms_g, "grid_points_per_sec": nc * n4 / (ms_g * 1e-3)}
     del pts, table, o
+    job = C4Pyramid(torch, None, device, 1, 0)
+    job.count_queries()
+    ms_p = _loop_ms(torch, job.step, 5, warm=2)
+    out["c4_kpconv_pyramid_stage"]["pyramid"] = job.report(ms_p, job.queries_per_step)
+    del job
     # ---- C5: one GPU's share of the 100k x 100k x 256 matching when the reference set is split 8 ways
     xq, y = c5_features(torch, device)
     ys = y[: C5_ROWS // 8].contiguous()
@@ -429,6 +437,100 @@ def per_config_single(torch, device):
                                         "ms": ms, "queries_per_sec": C5_ROWS / (ms * 1e-3), "tflops": tf,
                                         "mfma_frac": tf / MFMA_F32_PEAK_TFLOPS}
     return out
+
+
+C4_CLOUDS_PER_RANK, C4_POINTS = 16, 30000  # 8 samples per GPU x 2 clouds of ~30k points
+C4_STAGES, C4_VOXEL, C4_RADIUS, C4_LIMITS = 4, 0.025, 0.0625, (38, 36, 36, 38)
+
+
+class C4Pyramid:
+    """BASELINE config 4 under pack-mode batch sharding: the batch = 16 clouds per rank; every rank
+    generates the SAME whole batch from one seed (what a collate function would hand out), keeps its clouds through
+    sharding.shard_pack and builds the 4-stage grid + radius pyramid of those clouds
+    (ops.build_grid_and_radius_graph_pyramid; reference: models/graph_pyramid/graph_pyramid.py:9-63 under DDP,
+    utils/distributed.py:11-18).  No data-path collective.  verify(): this rank's first-stage table and first subsampling,
+    put into the whole batch's numbering, equal the rows a single process computes over the whole batch."""
+
+    def __init__(self, torch, dist, device, world, rank):
+        from vision3d_amd import ops, sharding
+
+        self.torch, self.dist, self.ops, self.sharding = torch, dist, ops, sharding
+        self.world, self.rank, self.device = world, rank, device
+        g = torch.Generator().manual_seed(11)
+        nc = C4_CLOUDS_PER_RANK * world
+        self.all_points = (torch.rand((nc * C4_POINTS, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(device)
+        self.all_lengths_host = torch.full((nc,), C4_POINTS, dtype=torch.long)
+        self.all_lengths = self.all_lengths_host.to(device)
+        shard = sharding.shard_pack(self.all_points, self.all_lengths_host, world, rank)
+        self.shard = shard
+        self.points = shard.points.contiguous()
+        self.lengths = self.all_lengths[shard.cloud_begin:shard.cloud_end].contiguous()
+        self.queries_per_step = None
+
+    def step(self):
+        return self.ops.build_grid_and_radius_graph_pyramid(self.points, self.lengths, C4_STAGES, C4_VOXEL, C4_RADIUS,
+                                                            list(C4_LIMITS))
+
+    def count_queries(self):
+        pyr = self.step()
+        rows = sum(t.shape[0] for key in ("neighbors", "subsampling", "upsampling") for t in pyr[key])
+        self.queries_per_step = rows
+        self.stage_points = [int(p.shape[0]) for p in pyr["points"]]
+        return rows
+
+    def verify(self):
+        torch, sh = self.torch, self.sharding
+        ok = True
+        if self.world > 1:
+            total = int(self.all_points.shape[0])
+            local_rows = self.shard.row_end - self.shard.row_begin
+            mine = self.ops.radius_search_pack_mode(self.points, self.points, self.lengths, self.lengths, C4_RADIUS,
+                                                    C4_LIMITS[0])
+            whole = self.ops.radius_search_pack_mode(self.all_points, self.all_points, self.all_lengths, self.all_lengths,
+                                                     C4_RADIUS, C4_LIMITS[0])
+            ok = torch.equal(sh.globalize_pack_table(mine, local_rows, self.shard.row_begin, total),
+                             whole[self.shard.row_begin:self.shard.row_end])
+            del whole, mine
+            sp, sl = self.ops.grid_subsample_pack_mode(self.points, self.lengths, 2 * C4_VOXEL)
+            wp, wl = self.ops.grid_subsample_pack_mode(self.all_points, self.all_lengths, 2 * C4_VOXEL)
+            sub = sh.shard_pack(wp, wl.cpu(), self.world, self.rank)
+            ok = ok and torch.equal(sp, sub.points) and torch.equal(sl.cpu(), sub.lengths)
+        flag = torch.tensor([1 if ok else 0], device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def report(self, ms, total_queries):
+        return {"workload": f"{C4_CLOUDS_PER_RANK} clouds x {C4_POINTS} pts per rank x {self.world} rank(s): {C4_STAGES}-stage "
+                            f"pyramid, voxel {C4_VOXEL} x2 per stage, radius {C4_RADIUS} x2 per stage, limits {list(C4_LIMITS)} "
+                            "(3 grid subsamplings + 10 radius searches per step)",
+                "sharding": f"pack-mode batch x{self.world} by lengths (sharding.shard_pack), no data-path collective",
+                "pyramid_ms": ms, "radius_queries_per_step_all_ranks": total_queries,
+                "radius_queries_per_sec": total_queries / (ms * 1e-3),
+                "input_points_per_sec": C4_CLOUDS_PER_RANK * C4_POINTS * self.world / (ms * 1e-3),
+                "stage_points_rank0": self.stage_points}
+
+
+def run_c4(torch, dist, device, world, rank, iters, max_over_ranks, bracket, warm=2):
+    """Times the sharded pyramid: barrier + synchronize either side, MAX over ranks, queries summed over ranks."""
+    job = C4Pyramid(torch, dist, device, world, rank)
+    ok = job.verify()
+    rows = job.count_queries()
+    for _ in range(warm):
+        job.step()
+    bracket()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        job.step()
+    bracket()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    total = rows
+    if dist is not None:
+        t = torch.tensor([rows], dtype=torch.int64, device=device)
+        dist.all_reduce(t)
+        total = int(t.item())
+    rep = dict(job.report(elapsed / iters * 1e3, total), equals_single_gpu_result=ok)
+    return job, elapsed, total, rep
 
 
 class C5Sharded:
@@ -560,6 +662,21 @@ def rank_main(args):
             dist.destroy_process_group()
         return
 
+    if args.workload == "c4_pyramid":
+        job, elapsed, total, rep = run_c4(torch, dist, device, world, rank, args.steps, max_over_ranks, bracket,
+                                          warm=args.warmup)
+        if rank == 0:
+            line.update(value=total * args.steps / elapsed, ms_per_step=elapsed / args.steps * 1e3, scaling="weak",
+                        metric="neighbor_queries_per_sec",
+                        config={"workload": "kpconv_pyramid_pack_mode", "sharding": rep["sharding"],
+                                "clouds_per_gpu": C4_CLOUDS_PER_RANK, "points_per_cloud": C4_POINTS},
+                        **{k: rep[k] for k in rep if k != "sharding"})
+            assert rep["equals_single_gpu_result"], "sharded pyramid differs from the single-process result"
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     inp = make_inputs(1234 + rank, device)  # every rank owns different clouds (batch sharding)
     # `--streams S` batches are in flight at once, each on its own HIP stream with its own buffers: FPS is a serial
     # chain that occupies only B of the 256 CUs, so the next batch's FPS runs under this batch's gathers / queries.
@@ -632,6 +749,12 @@ def rank_main(args):
         ex_ms = max_over_ranks(job.exchange_ms())
         c5 = dict(job.report(c5_ms), equals_single_gpu_result=ok, allgather_ms=ex_ms)
         del job
+    c4 = None
+    if dist is not None and not args.no_per_config:
+        torch.cuda.empty_cache()
+        job, _, _, c4 = run_c4(torch, dist, device, world, rank, 5, max_over_ranks, bracket)
+        _trace(f"c4 sharded pyramid: {c4['equals_single_gpu_result']}")
+        del job
 
     if rank == 0:
         per_op = {}
@@ -680,6 +803,8 @@ def rank_main(args):
         per_config = {}
         if c5 is not None:
             per_config["c5_matching_refset_sharded"] = c5
+        if c4 is not None:
+            per_config["c4_kpconv_pyramid_sharded"] = c4
         if world == 1 and not args.no_per_config:
             del steps[:]
             torch.cuda.empty_cache()
@@ -700,7 +825,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("c2", "c5_refset"), default="c2")
+    ap.add_argument("--workload", choices=("c2", "c5_refset", "c4_pyramid"), default="c2")
     ap.add_argument("--c5-k", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-config", action="store_true")

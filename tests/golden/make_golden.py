@@ -9,6 +9,8 @@ Two kinds of fixture, kept apart by file name:
     - vision3d/array_ops/ball_query.py          (cKDTree.query_ball_point)  -> ref_array_ball_query.npz
     - vision3d/array_ops/furthest_point_sample.py  (native_furthest_point_sample, NumPy) -> ref_array_fps.npz
     - vision3d/ops/knn_interpolate.py, ops/point_cloud_partition.py (pure torch once `.knn` resolves) -> ref_knn_ops.npz
+    - vision3d/ops/grid_subsample.py (naive :13-46 as is, fast :49-99), ops/conversion.py:7-83, and the pure-torch glue of
+      ops/radius_search.py:59-70 around a stand-in kNN                                    -> ref_pack_glue.npz
   The CUDA kernels themselves cannot be built or run here (no nvcc, no GPU) and ship no test vectors.
 * ``oracle_*.npz`` -- regression vectors of OUR CPU oracle on tie-stress inputs (lattices, duplicates, N<k,
   empty balls).  They pin the oracle against drift and give the GPU tests a file-based target; they are NOT
@@ -278,7 +280,7 @@ def make_pack_ops_fixtures():
     """ops/index_select.py, ops/pooling.py, ops/nearest_interpolate.py (pure torch) run on the CPU.  They import each other
     relatively, so they are loaded as submodules of an empty synthetic parent package whose __path__ is the reference's ops
     directory (the real ops/__init__.py pulls in pykeops and the unbuilt extension).  ops/knn_interpolate.py imports
-    ops/knn.py -> pykeops at module level and therefore stays unpinned."""
+    ops/knn.py -> pykeops at module level: its own logic is pinned separately by make_knn_ops_fixtures (ref_knn_ops.npz)."""
     import types
 
     parent = types.ModuleType("v3dref_ops")
@@ -466,6 +468,116 @@ def make_knn_ops_fixtures():
         _restore_modules(saved)
 
 
+def make_pack_glue_fixtures():
+    """The pure-torch pack-mode glue of the KPConv pyramid (models/graph_pyramid/graph_pyramid.py:9-63), run on the CPU:
+      * ops/grid_subsample.py:13-46 `naive_grid_subsample_pack_mode` exactly as it is (no `.cuda()` in it) and :49-99
+        `grid_subsample_pack_mode` with `Tensor.cuda` the identity (its one `.cuda()` is at :87);
+      * ops/conversion.py:7-83 (`pack_to_batch`, `batch_to_pack`, `batch_to_pack_with_lengths`), same identity;
+      * ops/radius_search.py:44-71 `radius_search_pack_mode` and :8-41 `naive_radius_search_pack_mode`.  The file imports
+        pykeops at :2 and `keops_knn` from `.knn` at :4; pykeops is absent, so `.knn` is the stand-in of
+        make_knn_ops_fixtures (the reference's own pairwise_distance + torch.topk) and `pykeops.torch.LazyTensor` is a
+        name that raises when called (the two functions pinned here never touch it).  This pins the GLUE -- padding with
+        1e10, per-cloud index offsets, the `> radius` mask -> sentinel, batch -> pack -- NOT pykeops' arithmetic, which stays
+        "parity unpinned" (DESIGN.md 2).  Inputs keep every pair at least 1e-5 away from the radius and are tie-free.
+    Empty clouds: both grid-subsample versions call `amin(0)` on the cloud's (0, 3) voxel tensor, which raises in torch, so
+    the reference defines no result for them; the fixture records that (`gs_empty_cloud_raises`)."""
+    import importlib
+    import types
+
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    saved = _synthetic_vision3d()
+    saved.update({n: sys.modules.get(n) for n in ("pykeops", "pykeops.torch")})
+    parent = types.ModuleType("v3dref_ops")
+    parent.__path__ = [os.path.join(REF, "ops")]
+    sys.modules["v3dref_ops"] = parent
+    try:
+        gs = importlib.import_module("v3dref_ops.grid_subsample")
+        conv = importlib.import_module("v3dref_ops.conversion")
+        rng = np.random.default_rng(20261201)
+        out = {}
+        # ---- grid subsampling: three clouds, negative coordinates, two voxel sizes
+        lengths = np.asarray([900, 1300, 700], dtype=np.int64)
+        pts = (rng.random((int(lengths.sum()), 3)).astype(np.float32) * np.float32([3.0, 3.0, 2.5])
+               - np.float32([1.0, 0.5, 0.0]))
+        out.update(gs_points=pts, gs_lengths=lengths)
+        tp, tl = torch.from_numpy(pts), torch.from_numpy(lengths)
+        for tag, vs in (("a", 0.3), ("b", 0.11)):
+            sp, sl = gs.grid_subsample_pack_mode(tp.clone(), tl, vs)
+            np_, nl = gs.naive_grid_subsample_pack_mode(tp.clone(), tl, vs)
+            out[f"gs_{tag}_voxel"] = np.float64(vs)
+            out[f"gs_{tag}_fast_points"], out[f"gs_{tag}_fast_lengths"] = sp.numpy(), sl.numpy()
+            out[f"gs_{tag}_naive_points"], out[f"gs_{tag}_naive_lengths"] = np_.numpy(), nl.numpy()
+        raised = []
+        for fn in (gs.grid_subsample_pack_mode, gs.naive_grid_subsample_pack_mode):
+            try:
+                fn(tp[:1600].clone(), torch.tensor([900, 0, 700]), 0.3)
+                raised.append(False)
+            except (RuntimeError, IndexError):
+                raised.append(True)
+        out["gs_empty_cloud_raises"] = np.asarray(raised)
+        # ---- conversion round trips
+        c_lengths = np.asarray([5, 0, 9, 3], dtype=np.int64)
+        packed = rng.standard_normal((int(c_lengths.sum()), 4)).astype(np.float32)
+        out.update(cv_lengths=c_lengths, cv_packed=packed)
+        for tag, max_len, fill in (("auto", None, 0.0), ("wide", 12, 1e10)):
+            bt, bm = conv.pack_to_batch(torch.from_numpy(packed), torch.from_numpy(c_lengths), max_length=max_len,
+                                        fill_value=fill)
+            out[f"cv_{tag}_batch"], out[f"cv_{tag}_masks"] = bt.numpy(), bm.numpy()
+            pk, pl = conv.batch_to_pack(bt, bm)
+            out[f"cv_{tag}_repacked"], out[f"cv_{tag}_relengths"] = pk.numpy(), pl.numpy()
+            pk2, pl2 = conv.batch_to_pack_with_lengths(bt, torch.from_numpy(c_lengths))
+            out[f"cv_{tag}_repacked_with_lengths"] = pk2.numpy()
+        pk3, pl3 = conv.batch_to_pack(bt)
+        out["cv_nomask_lengths"] = pl3.numpy()
+        out["cv_indices_from_lengths"] = conv._get_indices_from_lengths(torch.from_numpy(c_lengths), 12).numpy()
+        # ---- radius search glue around the stand-in kNN
+        pd = importlib.import_module("v3dref_ops.pairwise_distance")
+        knn_mod = types.ModuleType("v3dref_ops.knn")
+
+        def keops_knn(q_points, s_points, k):
+            d = pd.pairwise_distance(q_points, s_points, squared=False, strict=True)
+            return d.topk(k, dim=-1, largest=False)
+
+        knn_mod.keops_knn = keops_knn
+        sys.modules["v3dref_ops.knn"] = knn_mod
+        parent.knn = knn_mod
+        keops_pkg, keops_torch = types.ModuleType("pykeops"), types.ModuleType("pykeops.torch")
+        keops_pkg.__path__ = []
+
+        def _absent(*_a, **_k):
+            raise RuntimeError("pykeops is not installed in this container")
+
+        keops_torch.LazyTensor = _absent
+        keops_pkg.torch = keops_torch
+        sys.modules["pykeops"], sys.modules["pykeops.torch"] = keops_pkg, keops_torch
+        rs = importlib.import_module("v3dref_ops.radius_search")
+        ql = np.asarray([140, 60, 100], dtype=np.int64)
+        sl_ = np.asarray([300, 45, 220], dtype=np.int64)
+        radius, limit = 0.22, 24
+        seed = 20261202
+        while True:  # keep every pair clear of the radius so that fp32 rounding of any formulation cannot flip the mask
+            r2 = np.random.default_rng(seed)
+            q = r2.random((int(ql.sum()), 3), dtype=np.float32)
+            s = r2.random((int(sl_.sum()), 3), dtype=np.float32)
+            d = np.linalg.norm(q[:, None].astype(np.float64) - s[None].astype(np.float64), axis=-1)
+            if np.abs(d - radius).min() > 1e-5:
+                break
+            seed += 1
+        tq, ts = torch.from_numpy(q), torch.from_numpy(s)
+        fast = rs.radius_search_pack_mode(tq, ts, torch.from_numpy(ql), torch.from_numpy(sl_), radius, limit)
+        naive = rs.naive_radius_search_pack_mode(tq, ts, torch.from_numpy(ql), torch.from_numpy(sl_), radius, limit)
+        assert torch.equal(fast, naive)
+        out.update(rs_q=q, rs_s=s, rs_q_lengths=ql, rs_s_lengths=sl_, rs_radius=np.float64(radius),
+                   rs_limit=np.int64(limit), rs_table=fast.numpy(), rs_seed=np.int64(seed))
+        np.savez_compressed(os.path.join(HERE, "ref_pack_glue.npz"), **out)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        for name in [k_ for k_ in sys.modules if k_.startswith("v3dref_ops")]:
+            del sys.modules[name]
+        _restore_modules(saved)
+
+
 def make_oracle_fixtures():
     rng = np.random.default_rng(7)
     # lattice: 6x6x6 integer grid scaled by 0.25 -> massive distance ties, exactly representable
@@ -499,7 +611,9 @@ def make_oracle_fixtures():
 
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["reference", "select", "matching", "voxelize", "pack", "oracle", "fps", "knn_ops"]
+    which = sys.argv[1:] or ["reference", "select", "matching", "voxelize", "pack", "oracle", "fps", "knn_ops", "pack_glue"]
+    if "pack_glue" in which:
+        make_pack_glue_fixtures()
     if "fps" in which:
         make_fps_fixtures()
     if "knn_ops" in which:

@@ -60,6 +60,33 @@ def _worker(rank, world, port):
                 assert all(torch.equal(a, w) for a, w in zip(got, want)), f"sharded matching differs (k={k}, mutual={mutual})"
                 if mutual and k == 1:
                     assert int((got[0] < 500).sum()) >= 450  # the planted pairs are found
+        # ---- pack-mode batch sharding (BASELINE config 4): real radius-search / grid-subsample kernels on this rank's
+        # clouds; the gathered, globalized tables equal the single-process table; so does every stage of the pyramid
+        from vision3d_amd import ops
+
+        g = torch.Generator().manual_seed(9)
+        lens = torch.tensor([3000, 0, 1700, 2500, 900])
+        pts = (torch.rand((int(lens.sum()), 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(dev)
+        dlens = lens.to(dev)
+        table, qs, ss = sharding.radius_search_pack_sharded(pts, pts, lens, lens, 0.2, 20)
+        whole = sharding.gather_pack_tables(table, ss, pts.shape[0])
+        assert torch.equal(whole, ops.radius_search_pack_mode(pts, pts, dlens, dlens, 0.2, 20)), "sharded radius search"
+        mine = ops.build_grid_and_radius_graph_pyramid(qs.points.contiguous(), dlens[qs.cloud_begin:qs.cloud_end].contiguous(),
+                                                       3, 0.1, 0.25, [20, 18, 16])
+        full = ops.build_grid_and_radius_graph_pyramid(pts, dlens, 3, 0.1, 0.25, [20, 18, 16])
+        for i in range(3):
+            cur = sharding.shard_pack(full["points"][i], full["lengths"][i].cpu(), world, rank)
+            assert torch.equal(mine["points"][i], cur.points) and torch.equal(mine["lengths"][i].cpu(), cur.lengths)
+            n_cur, tot_cur = cur.row_end - cur.row_begin, full["points"][i].shape[0]
+            assert torch.equal(sharding.globalize_pack_table(mine["neighbors"][i], n_cur, cur.row_begin, tot_cur),
+                               full["neighbors"][i][cur.row_begin:cur.row_end]), f"pyramid neighbors, stage {i}"
+            if i < 2:
+                sub = sharding.shard_pack(full["points"][i + 1], full["lengths"][i + 1].cpu(), world, rank)
+                n_sub, tot_sub = sub.row_end - sub.row_begin, full["points"][i + 1].shape[0]
+                assert torch.equal(sharding.globalize_pack_table(mine["subsampling"][i], n_cur, cur.row_begin, tot_cur),
+                                   full["subsampling"][i][sub.row_begin:sub.row_end]), f"pyramid subsampling, stage {i}"
+                assert torch.equal(sharding.globalize_pack_table(mine["upsampling"][i], n_sub, sub.row_begin, tot_sub),
+                                   full["upsampling"][i][cur.row_begin:cur.row_end]), f"pyramid upsampling, stage {i}"
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         assert int(ones.item()) == world
@@ -91,6 +118,19 @@ def test_bench_starts_its_own_ranks_c5_refset_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_starts_its_own_ranks_c4_pyramid_on_one_gpu():
+    """BASELINE config 4 under pack-mode batch sharding, two ranks sharing the GPU over gloo: a line is printed under N > 1
+    and the per-rank tables equal the single-process ones."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                          "--workload", "c4_pyramid", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                         timeout=110)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _json_line(out.stdout)
+    assert line["n_gpus"] == 2 and line["equals_single_gpu_result"] is True and line["scaling"] == "weak"
+    assert line["radius_queries_per_step_all_ranks"] > 2 * 16 * 30000 and line["value"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_gpus2_over_rccl():
     import torch
 
@@ -102,6 +142,7 @@ def test_bench_gpus2_over_rccl():
     line = _json_line(out.stdout)
     assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2
     assert line["per_config"]["c5_matching_refset_sharded"]["equals_single_gpu_result"] is True
+    assert line["per_config"]["c4_kpconv_pyramid_sharded"]["equals_single_gpu_result"] is True
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -887,6 +887,37 @@ def test_grid_subsample_pack_native(ext, oracle_mod, case):
     assert np.array_equal(N_(got_p), want_p)  # same order, same summation order: bit-identical
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_grid_subsample_pack_vs_reference_fixture(ext, golden, tag):
+    """The kernel against the REFERENCE's own ops/grid_subsample.py (naive :13-46 and fast :49-99, run on the CPU by
+    tests/golden/make_golden.py): same order, lengths and barycentres bit for bit."""
+    from vision3d_amd import ops
+
+    g = golden("ref_pack_glue.npz")
+    got_p, got_l = ops.grid_subsample_pack_mode(T(g["gs_points"]), T(g["gs_lengths"]), float(g[f"gs_{tag}_voxel"]))
+    for version in ("fast", "naive"):
+        assert np.array_equal(N_(got_l), g[f"gs_{tag}_{version}_lengths"])
+        assert np.array_equal(N_(got_p), g[f"gs_{tag}_{version}_points"])
+
+
+def test_radius_search_pack_vs_reference_glue_fixture(ext, golden):
+    """The native pack-mode search, and the padded route through ops.conversion + keops_knn, against the reference's
+    ops/radius_search.py:44-71 run around a stand-in kNN (pins padding / offsets / mask / sentinel, not pykeops)."""
+    from vision3d_amd import ops
+    from vision3d_amd.ops import conversion as conv
+    from vision3d_amd.ops.radius_search import padded_radius_search_pack_mode
+
+    g = golden("ref_pack_glue.npz")
+    args = (T(g["rs_q"]), T(g["rs_s"]), T(g["rs_q_lengths"]), T(g["rs_s_lengths"]), float(g["rs_radius"]), int(g["rs_limit"]))
+    assert np.array_equal(N_(ops.radius_search_pack_mode(*args)), g["rs_table"])
+    assert np.array_equal(N_(padded_radius_search_pack_mode(*args)), g["rs_table"])
+    # the conversion mirrors on the device
+    bt, bm = conv.pack_to_batch(T(g["cv_packed"]), T(g["cv_lengths"]), max_length=12, fill_value=1e10)
+    assert np.array_equal(N_(bt), g["cv_wide_batch"]) and np.array_equal(N_(bm), g["cv_wide_masks"])
+    pk, pl = conv.batch_to_pack(bt, bm)
+    assert np.array_equal(N_(pk), g["cv_packed"]) and np.array_equal(N_(pl), g["cv_wide_relengths"])
+
+
 def test_c4_full_size_radius_search_count_and_grid_subsample(ext, oracle_mod):
     """BASELINE config 4 at full size: 16 clouds x 30,000 points in a 3 x 3 x 2.5 m box, radius 0.0625 with
     limit 38 and a denser radius 0.2 (more hits than the limit), voxel 0.025.  Radius search / count: oracle comparison on

@@ -129,6 +129,64 @@ def test_reference_set_sharding_equals_single_shot(world, n_ref, k):
         assert all(out.get(r) for r in range(world)), dict(out)
 
 
+def _pack_worker(rank, world, port, out):
+    """Pack-mode batch sharding (BASELINE config 4): every rank searches its own clouds with an injected CPU search (the
+    oracle's restatement of ops/radius_search.py:44-71); the per-rank tables, globalized and gathered, are the table one
+    process computes over the whole batch.  Clouds of different sizes, one of them empty, fewer clouds than ranks."""
+    import oracle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def cpu_search(q, s, ql, sl, radius, limit):
+            return torch.from_numpy(oracle.radius_search_pack(q.numpy(), s.numpy(), ql.numpy(), sl.numpy(), radius, limit))
+
+        ok = True
+        for q_lens, s_lens in (((40, 0, 25, 31, 17), (90, 12, 60, 75, 33)), ((50,), (120,))):
+            g = torch.Generator().manual_seed(3)  # same batch on every rank
+            ql, sl = torch.tensor(q_lens), torch.tensor(s_lens)
+            q = torch.rand((int(ql.sum()), 3), generator=g)
+            s = torch.rand((int(sl.sum()), 3), generator=g)
+            table, qs, ss = sharding.radius_search_pack_sharded(q, s, ql, sl, 0.25, 9, search_fn=cpu_search)
+            ok = ok and table.shape == (qs.row_end - qs.row_begin, 9)
+            ok = ok and bool((table <= ss.row_end - ss.row_begin).all())  # local numbering, local sentinel
+            whole = sharding.gather_pack_tables(table, ss, s.shape[0])
+            want = cpu_search(q, s, ql, sl, 0.25, 9)
+            ok = ok and torch.equal(whole, want)
+            # the shards tile the batch: clouds and rows, in rank order, nothing twice
+            spans = [None] * world
+            dist.all_gather_object(spans, (qs.cloud_begin, qs.cloud_end, qs.row_begin, qs.row_end))
+            ok = ok and spans[0][0] == 0 and spans[0][2] == 0 and spans[-1][1] == len(q_lens) and spans[-1][3] == q.shape[0]
+            ok = ok and all(spans[r][1] == spans[r + 1][0] and spans[r][3] == spans[r + 1][2] for r in range(world - 1))
+            ok = ok and torch.equal(qs.points, q[qs.row_begin:qs.row_end]) and torch.equal(qs.lengths, ql[qs.cloud_begin:qs.cloud_end])
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pack_mode_batch_sharding_equals_single_shot(world):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_pack_worker, args=(world, port, out), nprocs=world, join=True)
+        assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_shard_pack_bounds_and_globalize():
+    lengths = torch.tensor([5, 0, 9, 3, 7])
+    points = torch.arange(24 * 3, dtype=torch.float32).view(24, 3)
+    for world in (1, 2, 3, 8):
+        shards = [sharding.shard_pack(points, lengths, world, r) for r in range(world)]
+        assert torch.equal(torch.cat([s.points for s in shards]), points)
+        assert torch.equal(torch.cat([s.lengths for s in shards]), lengths)
+        assert all(int(s.lengths.sum()) == s.row_end - s.row_begin == s.points.shape[0] for s in shards)
+    table = torch.tensor([[0, 2, 4], [4, 4, 4]])
+    assert sharding.globalize_pack_table(table, 4, 10, 99).tolist() == [[10, 12, 99], [99, 99, 99]]
+    with pytest.raises(ValueError):
+        sharding.shard_pack(points[:20], lengths, 2, 1)
+
+
 def test_batch_bounds_cover_everything():
     for total in (0, 1, 7, 32, 33):
         for world in (1, 2, 3, 8):

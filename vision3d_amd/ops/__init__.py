@@ -21,6 +21,7 @@ from .mutual_topk_select import batch_mutual_topk_select, mutual_topk_select
 from .pack_gather import (global_avgpool_pack_mode, index_select, knn_interpolate, knn_interpolate_pack_mode,
                           local_maxpool_pack_mode, nearest_interpolate_pack_mode)
 from .pairwise_distance import pairwise_distance
+from .graph_pyramid import build_grid_and_radius_graph_pyramid
 from .grid_subsample import grid_subsample_pack_mode
 from .point_cloud_partition import ball_query_partition, get_point_to_node_indices, point_to_node_partition
 from .radius_search import naive_radius_search_pack_mode, radius_count_pack_mode, radius_search_pack_mode
@@ -37,5 +38,5 @@ __all__ = [
     "SuperPointMatchingGlobalTopk", "SuperPointMatchingMutualTopk", "voxelize", "voxelize_pack_mode", "knn_interpolate", "get_point_to_node_indices",
     "naive_radius_search_pack_mode",
     "index_select", "local_maxpool_pack_mode", "global_avgpool_pack_mode", "nearest_interpolate_pack_mode",
-    "knn_interpolate_pack_mode", "sa_group", "edge_group", "kpconv_gather", "kpconv", "point_to_node_partition", "ball_query_partition",
+    "knn_interpolate_pack_mode", "build_grid_and_radius_graph_pyramid", "sa_group", "edge_group", "kpconv_gather", "kpconv", "point_to_node_partition", "ball_query_partition",
 ]

@@ -6,11 +6,14 @@ import torch
 from torch import Tensor
 
 
-def _get_indices_from_lengths(lengths: Tensor, num_items: int) -> Tensor:
-    """Flat indices, in a (B * num_items) batch layout, of the valid items given per-cloud ``lengths``."""
+def _get_indices_from_lengths(lengths: Tensor, num_items: int, total: Optional[int] = None) -> Tensor:
+    """Flat indices, in a (B * num_items) batch layout, of the valid items given per-cloud ``lengths``.  ``total`` =
+    sum(lengths) when the caller already knows it (the packed tensor's row count): then nothing is read back from the
+    device; without it the sum is read once, because it is the shape of the result."""
     lengths = lengths.to(dtype=torch.long)
     starts = torch.cumsum(lengths, dim=0) - lengths  # first packed index of every cloud
-    total = int(lengths.sum().item())
+    if total is None:
+        total = int(lengths.sum().item())
     cloud = torch.repeat_interleave(torch.arange(lengths.shape[0], device=lengths.device), lengths, output_size=total)
     within = torch.arange(total, device=lengths.device) - starts[cloud]
     return cloud * num_items + within
@@ -37,7 +40,7 @@ def pack_to_batch(pack_tensor: Tensor, lengths: Tensor, max_length=None, fill_va
     batch_size = lengths.shape[0]
     if max_length is None:
         max_length = int(lengths.max().item())
-    tgt = _get_indices_from_lengths(lengths, max_length)
+    tgt = _get_indices_from_lengths(lengths, max_length, total=pack_tensor.shape[0])
     channels = pack_tensor.shape[1]
     batch_tensor = pack_tensor.new_full((batch_size * max_length, channels), fill_value)
     batch_tensor[tgt] = pack_tensor

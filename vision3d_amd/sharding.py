@@ -4,7 +4,10 @@ Two cases, one process per GPU (``torch.distributed``, backend ``nccl`` == RCCL 
 
 * Batched operators (FPS, ball query, kNN, three_nn, interpolation, gathers): clouds are independent, so the batch
   dimension is split contiguously across ranks -- ``batch_bounds`` / ``shard_batch`` -- and NO collective touches
-  the data path.
+  the data path.  Pack-mode inputs (``points (sum N_b, 3)`` + ``lengths (B,)``: KPConv / GeoTransformer pyramids,
+  BASELINE config 4) split the same way by ``lengths`` -- ``shard_pack`` -- each rank builds the neighbour tables of ITS
+  clouds; a table row holds indices into that rank's packed array (sentinel = that rank's row count), and
+  ``globalize_pack_table`` maps it onto the whole batch's numbering when a caller wants to compare or concatenate.
 * Scene-scale matching (N_q x N_s feature distance + top-k): the reference/support set is split into ``world``
   contiguous blocks; every rank runs the fused distance + top-k over its block (indices offset to global), then ONE
   exchange step -- an all-gather of the (N_q, k) partial lists, ``N_q * k * 12`` bytes per rank -- and a local
@@ -14,7 +17,7 @@ Two cases, one process per GPU (``torch.distributed``, backend ``nccl`` == RCCL 
 The search and merge kernels are injected (``search_fn`` / ``merge_fn``) only so the collective plumbing can be
 exercised with ``gloo`` on CPU in the tests; the defaults are the HIP kernels and there is no CPU fallback.
 """
-from typing import Callable, Optional, Tuple
+from typing import Callable, NamedTuple, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -33,6 +36,78 @@ def shard_batch(t: torch.Tensor, world: Optional[int] = None, rank: Optional[int
     rank = dist.get_rank() if rank is None else rank
     b, e = batch_bounds(t.shape[0], world, rank)
     return t[b:e]
+
+
+class PackShard(NamedTuple):
+    """This rank's contiguous clouds of a pack-mode batch."""
+    points: torch.Tensor   # (sum of this rank's lengths, C): a view of the batch's packed rows
+    lengths: torch.Tensor  # (clouds of this rank,): a view of the batch's lengths
+    cloud_begin: int       # first cloud of this rank in the batch
+    cloud_end: int
+    row_begin: int         # first packed row of this rank in the batch
+    row_end: int
+
+
+def shard_pack(points: torch.Tensor, lengths: torch.Tensor, world: Optional[int] = None,
+               rank: Optional[int] = None) -> PackShard:
+    """Pack-mode batch sharding ("pack-mode: split by ``lengths``"; the reference gives every DDP rank its
+    own samples through ``DistributedSampler``, utils/dataloader.py:90-93, and builds the pyramid per rank,
+    models/graph_pyramid/graph_pyramid.py:9-63).  Clouds [cloud_begin, cloud_end) = ``batch_bounds`` over
+    ``len(lengths)``; their packed rows are the contiguous range [row_begin, row_end) from a cumulative sum of the
+    lengths.  No collective; the two row bounds are read from ``lengths`` once (collate hands the lengths over on the
+    host; a device tensor costs one read-back)."""
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    cb, ce = batch_bounds(int(lengths.shape[0]), world, rank)
+    ends = torch.cumsum(lengths.to(torch.long), dim=0)
+    bounds = torch.stack([ends[cb - 1] if cb > 0 else ends.new_zeros(()), ends[ce - 1] if ce > 0 else ends.new_zeros(())])
+    rb, re = (int(v) for v in bounds.tolist())
+    if int(points.shape[0]) < re:
+        raise ValueError(f"shard_pack: lengths sum past row {re} but points has {int(points.shape[0])} rows")
+    return PackShard(points[rb:re], lengths[cb:ce], cb, ce, rb, re)
+
+
+def globalize_pack_table(table: torch.Tensor, local_rows: int, row_begin: int, global_rows: int) -> torch.Tensor:
+    """A neighbour table built on one rank's shard (entries in [0, local_rows), absent = ``local_rows``) in the numbering
+    of the whole batch (entries + ``row_begin``, absent = ``global_rows``): the per-rank tables of a sharded search,
+    globalized with the SUPPORT side's bounds and concatenated in rank order, equal the single-process table."""
+    return torch.where(table >= local_rows, torch.full_like(table, global_rows), table + row_begin)
+
+
+def _hip_radius_search(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit):
+    from .ops.radius_search import radius_search_pack_mode
+
+    return radius_search_pack_mode(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit)
+
+
+def radius_search_pack_sharded(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit,
+                               world: Optional[int] = None, rank: Optional[int] = None,
+                               search_fn: Callable = _hip_radius_search):
+    """``ops.radius_search_pack_mode`` (reference: ops/radius_search.py:44-71) on this rank's clouds of a pack-mode batch.
+    Returns (table over the rank's queries, in the rank's own support numbering; the query ``PackShard``; the support
+    ``PackShard``).  No collective: a query only ever sees supports of its own cloud."""
+    qs = shard_pack(q_points, q_lengths, world, rank)
+    ss = shard_pack(s_points, s_lengths, world, rank)
+    table = search_fn(qs.points, ss.points, qs.lengths, ss.lengths, radius, neighbor_limit)
+    return table, qs, ss
+
+
+def gather_pack_tables(table: torch.Tensor, supports: PackShard, global_rows: int, group=None) -> torch.Tensor:
+    """Off the data path (evaluation, tests): the whole batch's table on every rank from the per-rank tables of
+    ``radius_search_pack_sharded`` -- globalize, pad to the largest shard, ONE all-gather, trim.  Equal to the table a
+    single process computes over the whole batch."""
+    local_rows = supports.row_end - supports.row_begin
+    table = globalize_pack_table(table, local_rows, supports.row_begin, global_rows)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return table
+    world = dist.get_world_size(group)
+    counts = [None] * world
+    dist.all_gather_object(counts, int(table.shape[0]), group=group)
+    widest = max(counts)
+    if table.shape[0] < widest:
+        table = torch.cat([table, table.new_full((widest - table.shape[0], table.shape[1]), global_rows)], 0)
+    everything = _all_gather_rows(table, group)
+    return torch.cat([everything[r * widest:r * widest + counts[r]] for r in range(world)], 0)
 
 
 def _hip_search(x, y, k, index_offset):
