@@ -326,7 +326,7 @@ def cpu_baseline_reference(seed, q, budget_s=10.0):
             if time.perf_counter() - t0 > budget_s:
                 break
     el = time.perf_counter() - t0
-    return {
+    out = {
         "value": (len(SCALES) * M + N) * done / el,
         "unit": "queries/s",
         "cores": cores,
@@ -334,6 +334,42 @@ def cpu_baseline_reference(seed, q, budget_s=10.0):
         "sample": f"{done} of the {B} clouds of the same inputs: 3 query_ball_point scales + k=3 query per cloud, "
                   f"workers=-1, {el:.1f} s",
     }
+    out["fps"] = cpu_fps_reference(pts[0])
+    return out
+
+
+def cpu_fps_reference(cloud, budget_s=4.0):
+    """The reference's own CPU sampling, array_ops/furthest_point_sample.py:22-66 (`native_furthest_point_sample`),
+    restated as it is written there: a Python list of unselected indices, one float64 `np.linalg.norm` per (round, point),
+    running minima, strict `>` for the farthest.  One thread.  Bounded sample: as many ROUNDS of one cloud of the same
+    inputs as fit the budget (a whole M = 1024 sampling of 4096 points takes minutes this way); the rate is distance
+    updates per second, and `points_per_sec_extrapolated` = N / (time of a whole sampling at that rate), the unit of
+    `fps_points_per_sec`."""
+    import numpy as np
+
+    pts = np.asarray(cloud, dtype=np.float64)
+    n = pts.shape[0]
+    unselected = list(range(n))
+    running = np.full((n,), np.inf)
+    best, rounds, updates, t0 = 0, 0, 0, time.perf_counter()
+    while rounds < M - 1:
+        sel = unselected.pop(best)
+        best, best_d = -1, 0.0
+        for pos, p in enumerate(unselected):
+            d = min(running[p], np.linalg.norm(pts[p] - pts[sel]))
+            running[p] = d
+            if d > best_d:
+                best, best_d = pos, d
+        rounds += 1
+        updates += len(unselected)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    whole = sum(n - 1 - r for r in range(M - 1))  # updates of a whole sampling
+    return {"value": updates / el, "unit": "distance updates/s", "cores": 1,
+            "points_per_sec_extrapolated": n / (whole / (updates / el)),
+            "kind": "reference NumPy FPS restated (array_ops/furthest_point_sample.py:22-66)",
+            "sample": f"{rounds} of the {M - 1} rounds of one cloud of {n} points, {el:.1f} s"}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -708,6 +744,15 @@ def rank_main(args):
     bracket()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     _trace("c2 timed region done")
+    # spread: the same K-step region REPEATS - 1 more times (no events except the dominant kernel's); `value` stays the
+    # first region's, the one the contract describes
+    region_ms = [elapsed / args.steps * 1e3]
+    for _ in range(max(0, args.repeats - 1)):
+        bracket()
+        t0r = time.perf_counter()
+        run_steps(args.steps, timed=True)
+        bracket()
+        region_ms.append(max_over_ranks(time.perf_counter() - t0r) / args.steps * 1e3)
 
     # the same step with ONE batch in flight (what a single training step sees): not the headline, printed beside it
     run_steps(min(args.warmup, 3), nstr=1)
@@ -717,8 +762,9 @@ def rank_main(args):
     bracket()
     elapsed_single = max_over_ranks(time.perf_counter() - t1)
 
-    # ... and one batch in flight with the sampling cut into four launches, its consumers overlapped (PipelinedStep)
+    # ... and one batch in flight with the sampling cut into pieces (PipelinedStep.cuts), its consumers overlapped
     elapsed_pipe = None
+    pipe_cuts = None
     if world == 1:
         pstep = PipelinedStep(inp, device)
         for _ in range(min(args.warmup, 3)):
@@ -732,6 +778,7 @@ def rank_main(args):
         pipe_equal = bool(torch.equal(pstep.fps_idx, steps[0].fps_idx) and torch.equal(pstep.sgrad, steps[0].sgrad)
                           and all(torch.equal(torch.cat([pstep.g_feat[p][i] for p in range(pstep.pieces)], dim=2),
                                               steps[0].g_feat[i]) for i in range(len(SCALES))))
+        pipe_cuts = pstep.cuts
         del pstep
 
     c5 = None
@@ -778,13 +825,16 @@ def rank_main(args):
         line.update({
             "value": QUERIES_PER_STEP * args.steps * world / elapsed,
             "ms_per_step": ms_per_step,
+            "ms_per_step_min": float(np.min(region_ms)), "ms_per_step_median": float(np.median(region_ms)),
+            "ms_per_step_max": float(np.max(region_ms)), "timed_region_repeats": len(region_ms),
             "ms_per_step_single_stream": elapsed_single / args.steps * 1e3,
             "value_single_stream": QUERIES_PER_STEP * args.steps * world / elapsed_single,
             "ms_per_step_single_batch_pipelined": None if elapsed_pipe is None else elapsed_pipe / args.steps * 1e3,
             "single_batch_pipelined": None if elapsed_pipe is None else {
-                "what": "one batch in flight, FPS in 2 launches (v3d_fps_resume_f32: rounds 0-511, 512-1023), ball queries / "
-                        "gathers of the first half on a second stream under the sampling of the second; not the "
-                        "reference's call pattern",
+                "what": f"one batch in flight, FPS in {len(pipe_cuts) - 1} launches (v3d_fps_resume_f32: rounds "
+                        + ", ".join(f"{a}-{b - 1}" for a, b in zip(pipe_cuts[:-1], pipe_cuts[1:]))
+                        + "), ball queries / gathers of each piece on a second stream under the sampling of the next; "
+                          "not the reference's call pattern",
                 "equals_plain_step": pipe_equal},
             "scaling": "weak",
             "config": {"workload": "pointnet2_msg_fp_s3dis", "B_per_gpu": B, "N": N, "M": M,
@@ -827,6 +877,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=("c2", "c5_refset", "c4_pyramid"), default="c2")
     ap.add_argument("--c5-k", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is run this many times in all; `value` is the first region's, the "
+                         "min / median / max over the repeats ride along")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-config", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight (one HIP stream each)")

@@ -2,6 +2,8 @@
 // The kernel and its design notes live in fps_kernel.h.
 #include <math.h>
 
+#include <mutex>
+
 #include "fps_kernel.h"
 
 namespace v3d {
@@ -67,12 +69,18 @@ int v3d_fps_resume_f32(const float* points, float* distances, int64_t* indices, 
   else if (N <= 2048) V3D_FPS(512, 4, kFpsTable);
   else if (N <= 4096) V3D_FPS(512, 8, kFpsTable);
   else if (N <= 8192) {
-    static bool attr_set[64] = {};  // 128 KiB of dynamic LDS needs the opt-in, once per device
-    if (device < 0 || device >= 64 || !attr_set[device]) {
-      V3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<1024, 8, kFpsTable>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(float4)),
-                  what);
-      if (device >= 0 && device < 64) attr_set[device] = true;
+    // 128 KiB of dynamic LDS needs the opt-in, once per device; the per-device flags are the library's only state on
+    // this path and are read and written under a mutex (calls may come from several threads)
+    static std::mutex attr_mutex;
+    static bool attr_set[64] = {};
+    {
+      std::lock_guard<std::mutex> lock(attr_mutex);
+      if (device < 0 || device >= 64 || !attr_set[device]) {
+        V3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<1024, 8, kFpsTable>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(float4)),
+                    what);
+        if (device >= 0 && device < 64) attr_set[device] = true;
+      }
     }
     V3D_FPS(1024, 8, kFpsTable);
   } else if (N <= 16384) V3D_FPS(1024, 16, kFpsRegs);

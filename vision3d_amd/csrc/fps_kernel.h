@@ -223,7 +223,13 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float* __restrict__ 
   if (MODE == kFpsTable) __syncthreads();
   // old = 0 (:50,:57-59) -- or, resuming at round `first` (a multiple of 64; the running min-distances arrive in
   // dist_io as the previous launch left them), the sample of round first - 1
-  const int old = first > 0 ? (int)out_idx[first - 1] : 0;
+  // A resumed call trusts indices[:, :first] to come from the same (points, N) run; a value outside [0, N) (a buffer
+  // that was never sampled into) is read as point 0 instead of being used as an address.
+  int old = 0;
+  if (first > 0) {
+    const int64_t prev = out_idx[first - 1];
+    old = (prev >= 0 && prev < (int64_t)N) ? (int)prev : 0;
+  }
   float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
   int hist = 0;  // wave 0: lane j <-> the winner's priority of round (chunk * 64 + j); round 0 = priority 0 = point 0 (:51)
 

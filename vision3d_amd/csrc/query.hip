@@ -1322,8 +1322,9 @@ static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, co
   constexpr int QPW = 4;
   constexpr int TS = 1024;
   constexpr int kPerWg = kWavesPerBlock * QPW;
-  if (B > kKnnPackMaxClouds || total_s > (int64_t)INT32_MAX || ceil_div(total_q, kPerWg) + B > (int64_t)INT32_MAX) {
-    set_last_error("%s: at most 2^20 clouds, 2^31-1 supports and 2^35 queries per call", what);
+  // a cloud's query count lives in an int inside the plan (KnnPackPlan::q_len): the same 31-bit bound as the supports
+  if (B > kKnnPackMaxClouds || total_s > (int64_t)INT32_MAX || total_q > (int64_t)INT32_MAX) {
+    set_last_error("%s: at most 2^20 clouds, 2^31-1 supports and 2^31-1 queries per call", what);
     return V3D_ERR_SIZE_LIMIT;
   }
   DeviceGuard guard(device);

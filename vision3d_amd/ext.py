@@ -870,8 +870,10 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lenghts, radius):
     """(total_q, max_count) int64 neighbour table, ascending by distance, padded with total_s
     (csrc/cpu/radius_neighbors/radius_neighbors.cpp:5-93; keyword `s_lenghts` as registered, pybind.cpp:41).
 
-    Strict like the CPU code's nanoflann search (supports exactly AT the radius are left out: the table of the
-    inclusive search kernel is cut at the strict count of every query).  Difference: the table is at most 512 wide (the
+    Strict on ``radius - sqrt(d2) > 0`` (the count kernel's predicate: supports exactly AT the radius are left out; the
+    table of the inclusive search kernel is cut at that count).  The CPU code's nanoflann search tests ``d2 < radius *
+    radius`` in float (radius_neighbors.cpp:24,:60): the two predicates can disagree for a support within one ulp of the
+    sphere -- that boundary case is parity unpinned (the oracle uses the sqrt form too).  Difference: the table is at most 512 wide (the
     search kernel's list); a query with more than 512 neighbours raises instead of widening it further."""
     import numpy as np
 
