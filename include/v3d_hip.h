@@ -160,6 +160,24 @@ int v3d_group_gather_bwd_f64(const double* target_grads, const int64_t* indices,
                              int C, int N, int M, int K, void* workspace, size_t workspace_bytes, int device,
                              void* stream);
 
+/* The backward in two steps (no counterpart in the reference, whose atomics need no lists): v3d_scatter_build inverts an
+ * index tensor into `workspace` once -- indices (B, positions_per_batch) i64 over num_sources sources; mode 0 = gather /
+ * group_gather, mode 1 = three_interpolate (positions_per_batch = 3*Q; weights (B,Q,3) of elem_bytes 4 or 8 are stored in
+ * list order too) -- and v3d_scatter_apply_f32/_f64 writes source_grads (B,C,num_sources) from target_grads with those
+ * lists, as often as wanted: the xyz and the feature gather of one set-abstraction layer share their indices
+ * (layers/pointnet2.py:44-46), so does every channel width.  Results are bit-identical to the one-call entry points
+ * above.  `workspace`: v3d_scatter_workspace_bytes(B, num_sources, positions_per_batch) bytes, 256-B aligned, REQUIRED
+ * and owned by the caller for as long as the lists are used; apply only reads it.  `weights` in apply: the same tensor
+ * the build saw (mode 1; read by clouds with more than 4096 sources), NULL in mode 0. */
+int v3d_scatter_build(const int64_t* indices, const void* weights, int mode, int elem_bytes, int B, int num_sources,
+                      int64_t positions_per_batch, void* workspace, size_t workspace_bytes, int device, void* stream);
+int v3d_scatter_apply_f32(const float* target_grads, const float* weights, float* source_grads, int mode, int B, int C,
+                          int num_sources, int64_t positions_per_batch, const void* workspace, size_t workspace_bytes,
+                          int device, void* stream);
+int v3d_scatter_apply_f64(const double* target_grads, const double* weights, double* source_grads, int mode, int B, int C,
+                          int num_sources, int64_t positions_per_batch, const void* workspace, size_t workspace_bytes,
+                          int device, void* stream);
+
 /* ---- pairwise_distance / feature-space KNN ----------------------------------------------------------
  * v3d_pairwise_distance_f32 computes what ops/pairwise_distance.py:39-56 computes with torch.matmul and
  * 3-4 elementwise passes, in one kernel (fp32-input MFMA for the -2*x.y^T term, norms/clamp/sqrt in the

@@ -440,6 +440,97 @@ def test_three_interpolate(ext, oracle_mod, dtype):
         assert np.array_equal(N_(outb), wantb), (dtype, s, q)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_scatter_build_apply_equals_one_call_backward(ext, oracle_mod, dtype):
+    """v3d_scatter_build + v3d_scatter_apply (lists built ONCE per index tensor, summed with as often as wanted) against
+    the oracle and against the one-call entry points, bit for bit: both list layouts (<= 4096 sources in LDS, more in the
+    global CSR), both modes, two channel widths on one set of lists, refusals."""
+    from vision3d_amd import _lib
+
+    rng = np.random.default_rng(26)
+    tdt = T(np.zeros(1, dtype)).dtype
+    for (b, n, m, k) in ((2, 1024, 256, 16), (3, 4096, 512, 32), (2, 5000, 300, 7), (1, 50, 700, 3)):
+        idx = rng.integers(0, n, (b, m, k))
+        idx[:, : m // 3] = 0
+        ti = T(idx)
+        lists = ext.scatter_build(ti, n)
+        for c in (3, 10):  # the xyz and the feature gather of one layer share the lists
+            g = rng.standard_normal((b, c, m, k)).astype(dtype)
+            out = torch.full((b, c, n), 7.0, dtype=tdt, device=DEV)
+            ext.scatter_apply(T(g), lists, out)
+            assert np.array_equal(N_(out), oracle_mod.group_gather_backward(g, idx, n)), (dtype, n, m, k, c)
+            one = torch.empty_like(out)
+            ext.group_gather_backward(T(g), ti, one, n)
+            assert torch.equal(out, one)
+        i1 = np.ascontiguousarray(idx[..., 0])
+        l1 = ext.scatter_build(T(i1), n)
+        g1 = rng.standard_normal((b, 5, m)).astype(dtype)
+        out1 = torch.empty((b, 5, n), dtype=tdt, device=DEV)
+        ext.scatter_apply(T(g1), l1, out1)
+        assert np.array_equal(N_(out1), oracle_mod.gather_backward(g1, i1, n))
+        with pytest.raises(RuntimeError):  # lists of another index tensor
+            ext.scatter_apply(T(g1), lists, out1)
+    for (b, c, s_, q) in ((2, 33, 1024, 4096), (1, 4, 9000, 130), (3, 20, 256, 1001)):
+        idx = rng.integers(0, s_, (b, q, 3))
+        w = rng.random((b, q, 3)).astype(dtype)
+        g = rng.standard_normal((b, c, q)).astype(dtype)
+        tw = T(w)
+        lists = ext.scatter_build(T(idx), s_, tw)
+        out = torch.full((b, c, s_), 3.0, dtype=tdt, device=DEV)
+        ext.scatter_apply(T(g), lists, out)
+        assert np.array_equal(N_(out), oracle_mod.three_interpolate_backward(g, idx, w, s_)), (dtype, s_, q)
+    # straight through the C ABI: a missing or short workspace is refused, not allocated behind the caller's back
+    lib = _lib.lib()
+    ti = T(rng.integers(0, 64, (1, 100)))
+    rc = lib.v3d_scatter_build(ti.data_ptr(), None, 0, 4, 1, 64, 100, None, 0, torch.cuda.current_device(), None)
+    assert rc != 0 and lib.v3d_error_name(rc).decode() == "V3D_ERR_WORKSPACE"
+    small = torch.empty((256,), dtype=torch.uint8, device=DEV)
+    rc = lib.v3d_scatter_build(ti.data_ptr(), None, 0, 4, 1, 64, 100, small.data_ptr(), 16, torch.cuda.current_device(), None)
+    assert rc != 0 and lib.v3d_error_name(rc).decode() == "V3D_ERR_WORKSPACE"
+
+
+def test_autograd_wrappers_share_one_list_build_per_index_tensor(ext, monkeypatch):
+    """ops.group_gather / ops.gather / ops.three_interpolate backward: the lists are cached on the index tensor -- the xyz
+    and the feature gather of one set-abstraction layer (layers/pointnet2.py:44-46) build them once -- and an in-place edit
+    of the indices rebuilds them; gradients equal torch's own autograd of the same gathers."""
+    from vision3d_amd import ops
+
+    builds = []
+    real = ext.scatter_build
+    monkeypatch.setattr(ext, "scatter_build", lambda *a, **k: (builds.append(1), real(*a, **k))[1])
+    g = torch.Generator().manual_seed(3)
+    b, n, m, k = 2, 600, 128, 8
+    idx = torch.randint(0, n, (b, m, k), generator=g).to(DEV)
+    xyz = torch.randn((b, 3, n), generator=g).to(DEV).requires_grad_(True)
+    feat = torch.randn((b, 16, n), generator=g).to(DEV).requires_grad_(True)
+    (ops.group_gather(xyz, idx).sum() * 2 + (ops.group_gather(feat, idx) ** 2).sum()).backward()
+    assert len(builds) == 1
+    rx = xyz.detach().clone().requires_grad_(True)
+    rf = feat.detach().clone().requires_grad_(True)
+    flat = idx.view(b, 1, -1)
+    (torch.gather(rx, 2, flat.expand(b, 3, -1)).sum() * 2 + (torch.gather(rf, 2, flat.expand(b, 16, -1)) ** 2).sum()).backward()
+    torch.testing.assert_close(xyz.grad, rx.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(feat.grad, rf.grad, rtol=1e-5, atol=1e-4)
+    idx[0, 0, 0] = (idx[0, 0, 0] + 1) % n  # in-place edit: the cached lists are stale
+    feat.grad = None
+    ops.group_gather(feat, idx).sum().backward()
+    assert len(builds) == 2
+    want = torch.zeros((b, 16, n), device=DEV).scatter_add_(2, idx.view(b, 1, -1).expand(b, 16, -1),
+                                                            torch.ones((b, 16, m * k), device=DEV))
+    assert torch.equal(feat.grad, want)
+    # three_interpolate: lists keyed on the weights too
+    q = 500
+    i3 = torch.randint(0, m, (b, q, 3), generator=g).to(DEV)
+    w = torch.rand((b, q, 3), generator=g).to(DEV)
+    sf = torch.randn((b, 8, m), generator=g).to(DEV).requires_grad_(True)
+    ops.three_interpolate(sf, i3, w).sum().backward()
+    ops.three_interpolate(sf, i3, w).sum().backward()
+    assert len(builds) == 3
+    w2 = w.clone()
+    ops.three_interpolate(sf, i3, w2).sum().backward()
+    assert len(builds) == 4
+
+
 def test_backward_single_source_and_full_c2_interp(ext, oracle_mod):
     """Adversarial index tensors (every target on one source: one segment per chunk, carried across chunks) and the
     C2 three_interpolate backward at full size against the oracle."""

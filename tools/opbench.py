@@ -74,6 +74,10 @@ def main():
         gs = torch.empty((B, C, N), device=DEV)
         add(f"group_gather_bwd B{B} C{C} N{N} M{M} K{K}",
             lambda o=out, gi=gi, gs=gs, N=N: ext.group_gather_backward(o, gi, gs, N), nbytes / 1e3, "GB/s")
+        lists = ext.scatter_build(gi, N)  # what the autograd wrappers do: lists once per index tensor, then sums only
+        add(f"group_gather_bwd_apply B{B} C{C} N{N} M{M} K{K}",
+            lambda o=out, l=lists, gs=gs: ext.scatter_apply(o, l, gs), nbytes / 1e3, "GB/s")
+        add(f"group_gather_bwd_build B{B} C{C} N{N} M{M} K{K}", lambda gi=gi, N=N: ext.scatter_build(gi, N))
     B, C, S, Q = 32, 128, 1024, 4096
     src = torch.randn((B, C, S), generator=g).to(DEV)
     ii = torch.randint(0, S, (B, Q, 3), generator=g).to(DEV)
@@ -85,6 +89,9 @@ def main():
         nb / 1e3, "GB/s")
     add("three_interp_bwd C2", lambda out=out, ii=ii, w=w, gs=gs, S=S: ext.three_interpolate_backward(out, ii, w, gs, S),
         nb / 1e3, "GB/s")
+    l3 = ext.scatter_build(ii, S, w)
+    add("three_interp_bwd_apply C2", lambda out=out, l3=l3, gs=gs: ext.scatter_apply(out, l3, gs), nb / 1e3, "GB/s")
+    add("three_interp_bwd_build C2", lambda ii=ii, w=w, S=S: ext.scatter_build(ii, S, w))
     for (B, N, M, C) in ((32, 1024, 1024, 64), (1, 8192, 8192, 256), (1, 16384, 16384, 64)):
         x = torch.randn((B, N, C), generator=g).to(DEV)
         y = torch.randn((B, M, C), generator=g).to(DEV)

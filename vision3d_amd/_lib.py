@@ -56,6 +56,9 @@ SIGNATURES = {
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int] + _WS + _TAIL),
     "v3d_group_gather_bwd_f64": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int] + _WS + _TAIL),
+    "v3d_scatter_build": (_c_int, [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_i64] + _WS + _TAIL),
+    "v3d_scatter_apply_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_i64] + _WS + _TAIL),
+    "v3d_scatter_apply_f64": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_i64] + _WS + _TAIL),
     "v3d_pairwise_distance_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32] + _TAIL),
     "v3d_knn_feat_workspace_bytes": (_c_size, [_c_int, _c_int, _c_int, _c_int, _c_int]),

@@ -702,6 +702,18 @@ __device__ __forceinline__ double shr1_fill(double v, double fill) {
   const int hi = shr1_fill((int)(b >> 32), (int)(f >> 32));
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+__device__ __forceinline__ int shl1_fill(int v, int fill) {  // lane l <- lane l+1, lane 63 <- fill
+  return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float shl1_fill(float v, float fill) {
+  return __int_as_float(shl1_fill(__float_as_int(v), __float_as_int(fill)));
+}
+__device__ __forceinline__ double shl1_fill(double v, double fill) {
+  const long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
+  const int lo = shl1_fill((int)(b & 0xffffffffll), (int)(f & 0xffffffffll));
+  const int hi = shl1_fill((int)(b >> 32), (int)(f >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ float lane_permute(float v, int dst_lane) {  // lane l sends v to lane dst_lane
   return __int_as_float(__builtin_amdgcn_ds_permute(dst_lane << 2, __float_as_int(v)));
 }
@@ -828,6 +840,40 @@ __device__ __forceinline__ void lane_heap_sift(T (&hd)[R], int (&hi)[R], int siz
   }
 }
 
+// One slot per lane (size <= 64), no dependent walk at all.  Slot n's sibling is a neighbouring lane (children of p are
+// 2p+1 and 2p+2), so "n is the child its parent would descend into" (:21: the right one only if strictly greater) is two
+// whole-wave DPP shifts and two compares; the ballot of that, G, describes every bigger-child edge of the heap at once.
+// A slot lies on the root's bigger-child path iff G holds it and all its ancestors: one AND + compare against a per-lane
+// constant (`anc`, the slot's ancestor set incl. itself -- computed once per replay).  A path slot's path child is the one
+// of its two children G holds: ONE pull (ds_bpermute of distance and index) instead of fetching both children, and the
+// movers / the slot that takes v follow as in lane_heap_sift.  ~35 instructions and one LDS-crossbar round trip per
+// insertion; the six dependent v_readlane steps (VALU -> SGPR -> lane select, four wait states each) are gone.
+template <typename T>
+__device__ __forceinline__ void lane_heap_sift1(T& hd, int& hi, int size, T vd, int vi, int lane,
+                                                unsigned long long anc) {
+  const T left = shr1_fill(hd, hd), right = shl1_fill(hd, hd);
+  const unsigned long long in_heap = size >= 64 ? ~0ull : ((1ull << size) - 1ull);
+  const unsigned long long kOdd = 0xAAAAAAAAAAAAAAAAull;                    // left children (and bit 1...)
+  const unsigned long long right_bigger = __ballot(right > hd);            // slot n+1 strictly above slot n
+  const unsigned long long above_left = __ballot(hd > left);               // slot n strictly above slot n-1
+  // odd n (left child): chosen unless its right sibling exists and is strictly greater; even n >= 2 (right child):
+  // chosen iff strictly greater than its left sibling; bit 0 = the root
+  const unsigned long long good =
+      ((kOdd & ~(right_bigger & (in_heap >> 1))) | (~kOdd & above_left) | 1ull) & in_heap;
+  const bool on_path = (good & anc) == anc;
+  const int c0 = 2 * lane + 1;
+  const bool has0 = c0 < size;
+  const int big = ((good >> (c0 & 63)) & 1ull) ? c0 : c0 + 1;  // (lanes without children pull from a harmless lane)
+  const T cd = __shfl(hd, big & 63, 64);
+  const int ci = __shfl(hi, big & 63, 64);
+  const bool moves = on_path && has0 && !(vd > cd);  // :22 strict
+  const unsigned long long moved = __ballot(moves);
+  const bool parent_moved = lane == 0 || ((moved >> ((lane - 1) >> 1)) & 1ull);
+  const bool takes_v = on_path && !moves && parent_moved;
+  hd = moves ? cd : (takes_v ? vd : hd);
+  hi = moves ? ci : (takes_v ? vi : hi);
+}
+
 // Replay on the lane heap (R = 1: k <= 64, R = 2: k <= 127): the heap, the heap sort and the output never leave the
 // registers.
 template <typename T, int R>
@@ -850,30 +896,49 @@ __device__ void knn_exact_replay_lanes(const T* __restrict__ s_cloud, int N, int
       return n < 64 ? __builtin_amdgcn_readlane(hi[0], n & 63) : __builtin_amdgcn_readlane(hi[1], n & 63);
     else return __builtin_amdgcn_readlane(hi[0], n);
   };
-  T root_d = static_cast<T>(1e10);
-  T cx, cy, cz;
-  {
-    const int jj = lane < N ? lane : 0;
-    cx = s_cloud[(int64_t)jj * 3 + 0];
-    cy = s_cloud[(int64_t)jj * 3 + 1];
-    cz = s_cloud[(int64_t)jj * 3 + 2];
+  unsigned long long anc = 0;  // this lane's slot and its ancestors in the heap (lane_heap_sift1)
+  for (int a = lane;; a = (a - 1) >> 1) {
+    anc |= 1ull << a;
+    if (a == 0) break;
   }
-  for (int c0 = 0; c0 < N; c0 += 64) {
-    const bool valid = c0 + lane < N;
-    const T d = sq_dist(qx, qy, qz, cx, cy, cz);
-    {  // next chunk: in flight while this one's candidates go through the heap
-      const int jn = c0 + 64 + lane;
+  auto sift = [&](int size, T vd, int vi) {
+    if constexpr (R == 1) lane_heap_sift1<T>(hd[0], hi[0], size, vd, vi, lane, anc);
+    else lane_heap_sift<T, R>(hd, hi, size, vd, vi, lane);
+  };
+  T root_d = static_cast<T>(1e10);
+  // Supports come from global memory (L2) in groups of kAhead chunks of 64, the next group requested before this one
+  // goes through the heap: late in the scan most chunks hold no candidate, and with one chunk in flight the loop ran at
+  // one memory round trip per 64 supports (~20 us of a 59 us replay at N = 4096).
+  constexpr int kAhead = 4;
+  T cx[kAhead], cy[kAhead], cz[kAhead];
+  auto request = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int jn = base + u * 64 + lane;
       const int jj = jn < N ? jn : 0;
-      cx = s_cloud[(int64_t)jj * 3 + 0];
-      cy = s_cloud[(int64_t)jj * 3 + 1];
-      cz = s_cloud[(int64_t)jj * 3 + 2];
+      cx[u] = s_cloud[(int64_t)jj * 3 + 0];
+      cy[u] = s_cloud[(int64_t)jj * 3 + 1];
+      cz[u] = s_cloud[(int64_t)jj * 3 + 2];
     }
-    unsigned long long m = __ballot(valid && d < root_d);  // :80 strict
-    while (m) {
-      const int l = __builtin_ffsll((long long)m) - 1;
-      lane_heap_sift<T, R>(hd, hi, k, read_lane(d, l), c0 + l, lane);
-      root_d = read_lane(hd[0], 0);
-      m = __ballot(valid && d < root_d) & ~((2ull << l) - 1ull);
+  };
+  request(0);
+  for (int g0 = 0; g0 < N; g0 += 64 * kAhead) {
+    T dv[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) dv[u] = sq_dist(qx, qy, qz, cx[u], cy[u], cz[u]);
+    request(g0 + 64 * kAhead);
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int c0 = g0 + u * 64;
+      const bool valid = c0 + lane < N;
+      const T d = dv[u];
+      unsigned long long m = __ballot(valid && d < root_d);  // :80 strict
+      while (m) {
+        const int l = __builtin_ffsll((long long)m) - 1;
+        sift(k, read_lane(d, l), c0 + l);
+        root_d = read_lane(hd[0], 0);
+        m = __ballot(valid && d < root_d) & ~((2ull << l) - 1ull);
+      }
     }
   }
   for (int i = k - 1; i > 0; --i) {  // heap_sort :30-37: root <-> slot i, then sift the old slot i down a heap of i
@@ -888,7 +953,7 @@ __device__ void knn_exact_replay_lanes(const T* __restrict__ s_cloud, int N, int
         hi[R - 1] = top_i;
       }
     }
-    lane_heap_sift<T, R>(hd, hi, i, last_d, last_i, lane);
+    sift(i, last_d, last_i);
   }
   if (lane < k) {  // :88-91
     od[lane] = sqrt(hd[0]);

@@ -509,16 +509,101 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const T* __restrict__ 
     if (c0 + i < C) gsrc[((int64_t)b * C + c0 + i) * N + n] = acc[i];
 }
 
+// The backward in two steps, so that the lists of one index tensor serve every gradient that flows through it (the xyz
+// and the feature gather of one set-abstraction layer share `indices`, layers/pointnet2.py:44-46; every channel tile
+// does anyway): scatter_build inverts the indices into the workspace, scatter_apply sums with them.
 template <typename T, int MODE>
-int scatter_backward(const char* what, const T* gout, const int64_t* idx, const T* w, T* gsrc, int B, int C, int N,
-                     int64_t L, void* workspace, size_t workspace_bytes, int device, void* stream_) {
+static int scatter_check(const char* what, int B, int C, int N, int64_t L) {
   V3D_REQUIRE(B >= 0 && C >= 0 && N >= 0 && L >= 0, what, "negative dimension");
-  if (B == 0 || C == 0 || N == 0) return 0;
-  V3D_REQUIRE(gsrc && (L == 0 || (gout && idx)) && (MODE == 0 || L == 0 || w), what, "null pointer");
   if (B > kMaxGridYZ || L > (int64_t)INT32_MAX) {
     set_last_error("%s: B <= 65535 and targets per cloud < 2^31 required", what);
     return V3D_ERR_SIZE_LIMIT;
   }
+  if ((int64_t)ceil_div(C, 2) * B > (int64_t)INT32_MAX) {
+    set_last_error("%s: launch exceeds the grid limit", what);
+    return V3D_ERR_SIZE_LIMIT;
+  }
+  return 0;
+}
+
+static int scatter_check_workspace(const char* what, const void* base, size_t workspace_bytes, size_t need) {
+  if (base == nullptr || workspace_bytes < need || ((uintptr_t)base & 255) != 0) {
+    set_last_error("%s: workspace needs %zu bytes, 256-B aligned (got %zu)", what, need, workspace_bytes);
+    return V3D_ERR_WORKSPACE;
+  }
+  return 0;
+}
+
+// Enqueues the inversion of idx (B, L) over N sources into `base` (carve_workspace layout).  MODE 1 also stores the
+// weights in list order (chunked layout).  The device is current, sizes are checked, L > 0.
+template <typename T, int MODE>
+static int scatter_build_launch(const char* what, const int64_t* idx, const T* w, int B, int N, int64_t L, void* base,
+                                hipStream_t stream) {
+  ScatterWorkspace ws = carve_workspace(base, B, N, L);
+  const int64_t Lrow = MODE == 1 ? L / 3 : L;
+  const int nchunks = (int)std::max<int64_t>(1, ceil_div(Lrow, ChunkGeom<MODE>::P));
+  if (N <= kMaxLdsSources) {
+    constexpr int EMAX = ChunkGeom<MODE>::EMAX;
+    const size_t lds = sizeof(int) * (2 * (size_t)N + 1) + 2 * sizeof(uint16_t) * EMAX;
+    hipLaunchKernelGGL((csr_chunk_build_kernel<T, MODE>), dim3((unsigned)nchunks, (unsigned)B), dim3(kScatterThreads),
+                       lds, stream, idx, w, ws.seg, ws.ent, static_cast<T*>(ws.wsorted), N, L, nchunks,
+                       seg_stride(N, EMAX));
+  } else {
+    V3D_HIP_TRY(hipMemsetAsync(ws.cursor, 0, sizeof(int32_t) * (size_t)B * N, stream), what);
+    const unsigned xb = (unsigned)std::min<int64_t>(ceil_div(L, 256), 1024);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.cursor, N, L);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, stream, ws.cursor, ws.offsets, N);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.cursor, ws.unsorted, N,
+                       L);
+    hipLaunchKernelGGL(csr_rank_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.unsorted, ws.sorted, N,
+                       L);
+  }
+  return launch_status(what);
+}
+
+// Enqueues the sums: gsrc (B, C, N) fully written from gout with the lists `base` holds.
+template <typename T, int MODE>
+static int scatter_apply_launch(const char* what, const T* gout, const T* w, T* gsrc, int B, int C, int N, int64_t L,
+                                void* base, hipStream_t stream) {
+  ScatterWorkspace ws = carve_workspace(base, B, N, L);
+  const int64_t Lrow = MODE == 1 ? L / 3 : L;
+  const int nchunks = (int)std::max<int64_t>(1, ceil_div(Lrow, ChunkGeom<MODE>::P));
+  int rc = 0;
+  if (N <= kMaxLdsSources) {
+    // acc[N][CT] + tile[P][CT] + lists must fit 160 KiB: 32-byte channel vectors up to 1024 sources, else 16-byte
+    constexpr int kQuad = 16 / sizeof(T);
+    bool wide = false;
+    if constexpr (sizeof(T) == 4 && MODE == 1) {
+      // interpolation (short target rows, few chunks per workgroup): 16 channels per workgroup halve the list reads
+      // and the per-entry bookkeeping, and C/16 x B workgroups fill the chip in one round at C2
+      if (N <= 1024 && C >= 16) {
+        wide = true;
+        rc = launch_chunked<T, MODE, 16>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
+      }
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (!wide && N <= 1024) {
+        wide = true;
+        rc = launch_chunked<T, MODE, 8>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
+      }
+    }
+    if (!wide) rc = launch_chunked<T, MODE, kQuad>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
+    if (rc != 0) return rc;
+  } else {
+    constexpr int CT = 8;
+    dim3 grid((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, CT), (unsigned)B);
+    hipLaunchKernelGGL((segment_sum_kernel<T, MODE, CT>), grid, dim3(256), 0, stream, gout, w, ws.offsets, ws.sorted,
+                       gsrc, C, N, L, Lrow);
+  }
+  return launch_status(what);
+}
+
+template <typename T, int MODE>
+int scatter_backward(const char* what, const T* gout, const int64_t* idx, const T* w, T* gsrc, int B, int C, int N,
+                     int64_t L, void* workspace, size_t workspace_bytes, int device, void* stream_) {
+  if (int rc = scatter_check<T, MODE>(what, B, C, N, L)) return rc;
+  if (B == 0 || C == 0 || N == 0) return 0;
+  V3D_REQUIRE(gsrc && (L == 0 || (gout && idx)) && (MODE == 0 || L == 0 || w), what, "null pointer");
   DeviceGuard guard(device);
   if (guard.rc) return guard.rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -526,72 +611,17 @@ int scatter_backward(const char* what, const T* gout, const int64_t* idx, const 
     V3D_HIP_TRY(hipMemsetAsync(gsrc, 0, sizeof(T) * (size_t)B * C * N, stream), what);
     return 0;
   }
-  const int64_t Lrow = MODE == 1 ? L / 3 : L;
-  const bool chunked = N <= kMaxLdsSources;
-  const int nchunks = (int)std::max<int64_t>(1, ceil_div(Lrow, ChunkGeom<MODE>::P));
-  if ((int64_t)ceil_div(C, 2) * B > (int64_t)INT32_MAX) {
-    set_last_error("%s: launch exceeds the grid limit", what);
-    return V3D_ERR_SIZE_LIMIT;
-  }
   const size_t need = carve_workspace(nullptr, B, N, L).bytes;
   void* base = workspace;
   bool own = false;
   if (base == nullptr) {
     V3D_HIP_TRY(hipMallocAsync(&base, need, stream), what);
     own = true;
-  } else if (workspace_bytes < need || ((uintptr_t)base & 255) != 0) {
-    set_last_error("%s: workspace needs %zu bytes, 256-B aligned (got %zu)", what, need, workspace_bytes);
-    return V3D_ERR_WORKSPACE;
+  } else if (int rc = scatter_check_workspace(what, base, workspace_bytes, need)) {
+    return rc;
   }
-  ScatterWorkspace ws = carve_workspace(base, B, N, L);
-  int rc = 0;
-  do {
-    if (chunked) {
-      constexpr int EMAX = ChunkGeom<MODE>::EMAX;
-      const size_t lds = sizeof(int) * (2 * (size_t)N + 1) + 2 * sizeof(uint16_t) * EMAX;
-      hipLaunchKernelGGL((csr_chunk_build_kernel<T, MODE>), dim3((unsigned)nchunks, (unsigned)B),
-                         dim3(kScatterThreads), lds, stream, idx, w, ws.seg, ws.ent, static_cast<T*>(ws.wsorted), N, L,
-                         nchunks, seg_stride(N, EMAX));
-      // acc[N][CT] + tile[P][CT] + lists must fit 160 KiB: 32-byte channel vectors up to 1024 sources, else 16-byte
-      constexpr int kQuad = 16 / sizeof(T);
-      bool wide = false;
-      if constexpr (sizeof(T) == 4 && MODE == 1) {
-        // interpolation (short target rows, few chunks per workgroup): 16 channels per workgroup halve the list reads
-        // and the per-entry bookkeeping, and C/16 x B workgroups fill the chip in one round at C2
-        if (N <= 1024 && C >= 16) {
-          wide = true;
-          rc = launch_chunked<T, MODE, 16>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
-        }
-      }
-      if constexpr (sizeof(T) == 4) {
-        if (!wide && N <= 1024) {
-          wide = true;
-          rc = launch_chunked<T, MODE, 8>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
-        }
-      }
-      if (!wide) rc = launch_chunked<T, MODE, kQuad>(what, gout, ws, gsrc, B, C, N, Lrow, nchunks, stream);
-      if (rc != 0) break;
-    } else {
-      hipError_t e = hipMemsetAsync(ws.cursor, 0, sizeof(int32_t) * (size_t)B * N, stream);
-      if (e != hipSuccess) {
-        set_last_error("%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
-        rc = (int)e;
-        break;
-      }
-      const unsigned xb = (unsigned)std::min<int64_t>(ceil_div(L, 256), 1024);
-      hipLaunchKernelGGL(csr_count_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.cursor, N, L);
-      hipLaunchKernelGGL(csr_scan_kernel, dim3(B), dim3(1024), 0, stream, ws.cursor, ws.offsets, N);
-      hipLaunchKernelGGL(csr_fill_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.cursor, ws.unsorted,
-                         N, L);
-      hipLaunchKernelGGL(csr_rank_kernel, dim3(xb, B), dim3(256), 0, stream, idx, ws.offsets, ws.unsorted, ws.sorted,
-                         N, L);
-      constexpr int CT = 8;
-      dim3 grid((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, CT), (unsigned)B);
-      hipLaunchKernelGGL((segment_sum_kernel<T, MODE, CT>), grid, dim3(256), 0, stream, gout, w, ws.offsets,
-                         ws.sorted, gsrc, C, N, L, Lrow);
-    }
-    rc = launch_status(what);
-  } while (0);
+  int rc = scatter_build_launch<T, MODE>(what, idx, w, B, N, L, base, stream);
+  if (rc == 0) rc = scatter_apply_launch<T, MODE>(what, gout, w, gsrc, B, C, N, L, base, stream);
   if (own) {
     hipError_t e = hipFreeAsync(base, stream);
     if (rc == 0 && e != hipSuccess) {
@@ -600,6 +630,45 @@ int scatter_backward(const char* what, const T* gout, const int64_t* idx, const 
     }
   }
   return rc;
+}
+
+template <typename T>
+static int scatter_build_entry(const int64_t* idx, const T* w, int mode, int B, int N, int64_t L, void* workspace,
+                               size_t workspace_bytes, int device, void* stream_) {
+  const char* what = "scatter_build";
+  V3D_REQUIRE(mode == 0 || mode == 1, what, "mode is 0 (gather / group_gather) or 1 (three_interpolate)");
+  V3D_REQUIRE(mode == 0 || L % 3 == 0, what, "three_interpolate lists hold 3 entries per target");
+  if (int rc = scatter_check<T, 0>(what, B, 1, N, L)) return rc;
+  if (B == 0 || N == 0 || L == 0) return 0;
+  V3D_REQUIRE(idx && (mode == 0 || w), what, "null pointer");
+  if (int rc = scatter_check_workspace(what, workspace, workspace_bytes, carve_workspace(nullptr, B, N, L).bytes)) return rc;
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  return mode == 0 ? scatter_build_launch<T, 0>(what, idx, w, B, N, L, workspace, stream)
+                   : scatter_build_launch<T, 1>(what, idx, w, B, N, L, workspace, stream);
+}
+
+template <typename T>
+static int scatter_apply_entry(const T* gout, const T* w, T* gsrc, int mode, int B, int C, int N, int64_t L,
+                               const void* workspace, size_t workspace_bytes, int device, void* stream_) {
+  const char* what = "scatter_apply";
+  V3D_REQUIRE(mode == 0 || mode == 1, what, "mode is 0 (gather / group_gather) or 1 (three_interpolate)");
+  V3D_REQUIRE(mode == 0 || L % 3 == 0, what, "three_interpolate lists hold 3 entries per target");
+  if (int rc = scatter_check<T, 0>(what, B, C, N, L)) return rc;
+  if (B == 0 || C == 0 || N == 0) return 0;
+  V3D_REQUIRE(gsrc && (L == 0 || gout) && (mode == 0 || L == 0 || w), what, "null pointer");
+  DeviceGuard guard(device);
+  if (guard.rc) return guard.rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (L == 0) {
+    V3D_HIP_TRY(hipMemsetAsync(gsrc, 0, sizeof(T) * (size_t)B * C * N, stream), what);
+    return 0;
+  }
+  if (int rc = scatter_check_workspace(what, workspace, workspace_bytes, carve_workspace(nullptr, B, N, L).bytes)) return rc;
+  void* base = const_cast<void*>(workspace);  // read only by the kernels
+  return mode == 0 ? scatter_apply_launch<T, 0>(what, gout, w, gsrc, B, C, N, L, base, stream)
+                   : scatter_apply_launch<T, 1>(what, gout, w, gsrc, B, C, N, L, base, stream);
 }
 
 // used by interp.hip
@@ -673,6 +742,28 @@ int v3d_three_interp_bwd_noalloc_f32(const float* g, const int64_t* idx, const f
   // from here on the array is `ptr`, never its name: the kernels take it as the workspace argument
   return scatter_backward<float, 1>(what, g, idx, w, gs, B, C, S, (int64_t)Q * 3, ptr, kNoAllocScratchBytes, device,
                                     stream);
+}
+
+int v3d_scatter_build(const int64_t* indices, const void* weights, int mode, int elem_bytes, int B, int num_sources,
+                      int64_t positions_per_batch, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (mode == 1 && elem_bytes == 8)
+    return v3d::scatter_build_entry<double>(indices, static_cast<const double*>(weights), mode, B, num_sources,
+                                            positions_per_batch, workspace, workspace_bytes, device, stream);
+  if (mode == 1 && elem_bytes != 4) return v3d::invalid("scatter_build", "elem_bytes is 4 (f32) or 8 (f64)");
+  return v3d::scatter_build_entry<float>(indices, static_cast<const float*>(weights), mode, B, num_sources,
+                                         positions_per_batch, workspace, workspace_bytes, device, stream);
+}
+int v3d_scatter_apply_f32(const float* target_grads, const float* weights, float* source_grads, int mode, int B, int C,
+                          int num_sources, int64_t positions_per_batch, const void* workspace, size_t workspace_bytes,
+                          int device, void* stream) {
+  return v3d::scatter_apply_entry<float>(target_grads, weights, source_grads, mode, B, C, num_sources,
+                                         positions_per_batch, workspace, workspace_bytes, device, stream);
+}
+int v3d_scatter_apply_f64(const double* target_grads, const double* weights, double* source_grads, int mode, int B, int C,
+                          int num_sources, int64_t positions_per_batch, const void* workspace, size_t workspace_bytes,
+                          int device, void* stream) {
+  return v3d::scatter_apply_entry<double>(target_grads, weights, source_grads, mode, B, C, num_sources,
+                                          positions_per_batch, workspace, workspace_bytes, device, stream);
 }
 
 size_t v3d_scatter_workspace_bytes(int B, int num_sources, int64_t positions_per_batch) {

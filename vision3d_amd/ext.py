@@ -201,6 +201,52 @@ def group_gather_forward(sources, indices, targets):
     _gather_forward("group_gather_forward", "group_gather_forward_kernel", sources, indices, targets, grouped=True)
 
 
+class ScatterLists:
+    """The inversion of one index tensor (v3d_scatter_build): the device workspace that holds the lists and what they were
+    built for.  Kept by the caller (the ops cache it on the index tensor) and handed to every backward that flows through
+    those indices."""
+    __slots__ = ("workspace", "mode", "B", "N", "L", "weights")
+
+    def __init__(self, workspace, mode, B, N, L, weights):
+        self.workspace, self.mode, self.B, self.N, self.L, self.weights = workspace, mode, B, N, L, weights
+
+
+def scatter_build(indices, num_sources, weights=None):
+    """Not in the reference's extension (its backward kernels scatter with atomics): inverts ``indices`` -- (B, M) /
+    (B, M, K) of gather / group_gather, or the (B, Q, 3) table of three_interpolate together with its ``weights`` -- into
+    per-source lists once; ``scatter_apply`` then only sums, as often as wanted."""
+    _check_cuda_contiguous(indices, "indices")
+    _check_long(indices, "indices")
+    mode, elem = 0, 4
+    if weights is not None:
+        _check_cuda_contiguous(weights, "weights")
+        _floating_suffix(weights, "three_interpolate_backward_kernel")
+        if tuple(weights.shape) != tuple(indices.shape) or indices.dim() != 3 or indices.size(2) != 3:
+            raise RuntimeError("scatter_build: three_interpolate lists need indices and weights of shape (B, Q, 3)")
+        mode, elem = 1, weights.element_size()
+    B, N = indices.size(0), int(num_sources)
+    L = indices.numel() // max(B, 1)
+    dev, stream = _where(indices)
+    nbytes = _lib.lib().v3d_scatter_workspace_bytes(B, N, L)
+    ws = torch.empty((max(nbytes, 256) + 256,), dtype=torch.uint8, device=indices.device)
+    ws = ws[(-ws.data_ptr()) % 256:][:max(nbytes, 256)]  # 256-byte aligned, owned by the lists (not the shared scratch)
+    rc = _lib.lib().v3d_scatter_build(indices.data_ptr(), 0 if weights is None else weights.data_ptr(), mode, elem, B, N, L,
+                                      ws.data_ptr(), ws.numel(), dev, stream)
+    _lib.check(rc, "scatter_build")
+    return ScatterLists(ws, mode, B, N, L, weights)
+
+
+def _scatter_apply(name, target_grads, lists, source_grads, sfx, L, mode):
+    B, C = target_grads.size(0), target_grads.size(1)
+    if (lists.mode, lists.B, lists.L, lists.N) != (mode, B, L, source_grads.size(2)):
+        raise RuntimeError(f"{name}: the lists were built for another index tensor (mode / B / positions / sources differ)")
+    dev, stream = _where(target_grads)
+    fn = getattr(_lib.lib(), "v3d_scatter_apply_" + sfx)
+    w = 0 if lists.weights is None else lists.weights.data_ptr()
+    _lib.check(fn(target_grads.data_ptr(), w, source_grads.data_ptr(), mode, B, C, lists.N, L, lists.workspace.data_ptr(),
+                  lists.workspace.numel(), dev, stream), name)
+
+
 def _gather_backward(name, kernel, target_grads, indices, source_grads, num_sources, grouped):
     _check_cuda_contiguous(target_grads, "target_grads")
     _check_cuda_contiguous(indices, "indices")
@@ -235,6 +281,22 @@ def gather_backward(target_grads, indices, source_grads, num_sources):
 def group_gather_backward(target_grads, indices, source_grads, num_sources):
     _gather_backward("group_gather_backward", "group_gather_backward_kernel", target_grads, indices, source_grads,
                      num_sources, grouped=True)
+
+
+def scatter_apply(target_grads, lists, source_grads):
+    """Not in the reference's extension: the backward of gather / group_gather / three_interpolate with the lists of
+    ``scatter_build`` -- ``source_grads`` (B, C, num_sources) fully written from ``target_grads`` (B, C, M) / (B, C, M, K) /
+    (B, C, Q), bit-identical to ``gather_backward`` / ``group_gather_backward`` / ``three_interpolate_backward``."""
+    _check_cuda_contiguous(target_grads, "target_grads")
+    _check_cuda_contiguous(source_grads, "source_grads")
+    kernel = "three_interpolate_backward_kernel" if lists.mode == 1 else "group_gather_backward_kernel"
+    sfx = _floating_suffix(target_grads, kernel)
+    _same_dtype("scatter_apply", target_grads, source_grads)
+    if lists.weights is not None:
+        _same_dtype("scatter_apply", target_grads, lists.weights)
+    positions = target_grads.numel() // max(target_grads.size(0) * target_grads.size(1), 1)
+    _scatter_apply("scatter_apply", target_grads, lists, source_grads, sfx, positions * (3 if lists.mode == 1 else 1),
+                   lists.mode)
 
 
 def three_nn(q_points, s_points, tnn_distances, tnn_indices):
@@ -931,17 +993,23 @@ def sample_nodes_with_fps(points, min_distance, num_samples):
         dist = torch.full((1, n), 1e10, dtype=torch.float32, device=p.device)
         idx = torch.zeros((1, take), dtype=torch.long, device=p.device)
         furthest_point_sample(p.unsqueeze(0), dist, idx, take)
-        idx = idx[0]
+        host_idx = idx[0].cpu().numpy()  # the entry point returns NumPy: this copy is its one synchronisation per pass
         if min_distance is None or min_distance <= 0:
-            return idx.cpu().numpy()
-        chosen = p[idx]
-        gaps = torch.cdist(chosen.double(), chosen.double())
-        gaps = gaps.masked_fill(torch.ones_like(gaps, dtype=torch.bool).triu(), float("inf")).min(dim=1)[0]
-        below = torch.nonzero(gaps.float() < float(min_distance)).view(-1)  # gaps[0] = inf: the first sample always stays
-        if below.numel():
-            return idx[: int(below[0].item())].cpu().numpy()
+            return host_idx
+        # selection distance of sample j = its distance to the nearest of the samples before it (float64, on the host:
+        # the result is host-side anyway, and `take` <= 1024 on the first pass)
+        chosen = np.asarray(points, dtype=np.float32)[host_idx].astype(np.float64)
+        gaps = np.full((take,), np.inf)
+        for j0 in range(0, take, 256):
+            blk = chosen[j0:j0 + 256]
+            d = np.sqrt(((blk[:, None, :] - chosen[None, :j0 + blk.shape[0], :]) ** 2).sum(-1))
+            d[np.arange(blk.shape[0])[:, None] + j0 <= np.arange(d.shape[1])[None, :]] = np.inf  # earlier samples only
+            gaps[j0:j0 + blk.shape[0]] = d.min(axis=1)
+        below = np.nonzero(gaps.astype(np.float32) < np.float32(min_distance))[0]  # gaps[0] = inf: the first always stays
+        if below.size:
+            return host_idx[: int(below[0])]
         if take >= want:
-            return idx.cpu().numpy()
+            return host_idx
         take = min(want, take * 4)
 
 

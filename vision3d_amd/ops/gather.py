@@ -3,6 +3,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 from .. import ext
+from ._scatter_lists import scatter_lists
 
 
 class GatherFunction(Function):
@@ -27,7 +28,8 @@ class GatherFunction(Function):
         grads = grad_outputs.transpose(1, 2) if ctx.transposed else grad_outputs
         grads = grads.contiguous()
         grad_inputs = grads.new_empty((grads.shape[0], grads.shape[1], ctx.num_inputs))  # (B, C, N)
-        ext.gather_backward(grads, indices, grad_inputs, ctx.num_inputs)
+        # (the reference calls ext.gather_backward here, :61; same sums, the lists built once per index tensor)
+        ext.scatter_apply(grads, scatter_lists(indices, ctx.num_inputs), grad_inputs)
         if ctx.transposed:
             grad_inputs = grad_inputs.transpose(1, 2).contiguous()
         return grad_inputs, None, None

@@ -17,8 +17,10 @@ def knn_points(
         s_points = s_points.transpose(1, 2)
     q_points = q_points.contiguous()
     s_points = s_points.contiguous()
-    knn_distances = q_points.new_zeros((q_points.shape[0], q_points.shape[1], k))
-    knn_indices = torch.zeros((q_points.shape[0], q_points.shape[1], k), dtype=torch.long, device=q_points.device)
+    # (the reference zero-fills both, ops/knn_points.py:33-34; the kernel writes every slot -- the (1e5, 0) sentinels of
+    # M < k included -- so nothing is filled here)
+    knn_distances = q_points.new_empty((q_points.shape[0], q_points.shape[1], k))
+    knn_indices = torch.empty((q_points.shape[0], q_points.shape[1], k), dtype=torch.long, device=q_points.device)
     ext.knn(q_points, s_points, knn_distances, knn_indices, k)  # the reference calls `ext_module.knn` here (:36)
     if return_distance:
         return knn_distances, knn_indices

@@ -3,6 +3,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 from .. import ext
+from ._scatter_lists import scatter_lists
 
 
 class _ThreeInterpolateFunction(Function):
@@ -27,7 +28,8 @@ class _ThreeInterpolateFunction(Function):
         grads = q_grads.transpose(1, 2) if ctx.transposed else q_grads
         grads = grads.contiguous()
         s_grads = grads.new_empty((grads.shape[0], grads.shape[1], ctx.num_supports))  # (B, C, M)
-        ext.three_interpolate_backward(grads, indices, weights, s_grads, ctx.num_supports)
+        # (the reference calls ext.three_interpolate_backward here, :57; same sums, the lists built once per table)
+        ext.scatter_apply(grads, scatter_lists(indices, ctx.num_supports, weights), s_grads)
         if ctx.transposed:
             s_grads = s_grads.transpose(1, 2).contiguous()
         return s_grads, None, None, None
