@@ -238,20 +238,24 @@ int v3d_radius_count_pack_f32(const float* q_points, const float* s_points, cons
  * edge `voxel_size` = mean of the voxel's points (summed in input order, fp32), ordered by (cloud, vx, vy, vz) like
  * torch.unique of the reference's hash.  sampled_points must hold `total` rows; the number actually written goes to
  * *num_sampled (device scalar; -1 if a cloud spans more than 2^18 voxels along an axis or holds NaN), per-cloud
- * counts to sampled_lengths (B,).  Scratch is allocated stream-ordered inside (hipMallocAsync). */
+ * counts to sampled_lengths (B,).  Scratch: `workspace` of v3d_grid_subsample_workspace_bytes(B, total, C) bytes (C = 0
+ * here; the feature channels of v3d_voxelize_pack_f32), 256-B aligned, owned by the caller like every other buffer -- or
+ * NULL for a stream-ordered allocation inside (hipMallocAsync / hipFreeAsync on `stream`). */
+size_t v3d_grid_subsample_workspace_bytes(int B, int64_t total, int C);
 int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, float* sampled_points,
                                 int64_t* sampled_lengths, int64_t* num_sampled, int B, int64_t total, float voxel_size,
-                                int device, void* stream);
+                                void* workspace, size_t workspace_bytes, int device, void* stream);
 /* v3d_voxelize_pack_f32 replaces voxelize_pack_mode (vision3d/ops/voxelize.py:6-63; its batch form `voxelize` :66-100 is
  * pack/batch conversion around it): the same per-voxel reduction with voxel = floor(p / voxel_size) (:22, a correctly
  * rounded fp32 division; grid subsampling multiplies by 1 / voxel_size instead), and three more outputs: voxels (M,3)
  * int64 = the integer voxel coordinates (:43-44), voxel_feats (M,C) = the voxel means of feats (N,C) (:57-60; feats = NULL,
  * C = 0 without features), nodes (M,3) = the voxel means of the points (:46-49), voxel_lengths (B,) (:51-54).  Output
  * order = torch.unique of the hash = ascending (cloud, vx, vy, vz); sums run in input order (no atomics): bit-reproducible.
- * Output buffers hold `total` rows; *num_voxels = M, or -1 as above. */
+ * Output buffers hold `total` rows; *num_voxels = M, or -1 as above.  Workspace as for grid subsampling (with this C). */
 int v3d_voxelize_pack_f32(const float* points, const int64_t* lengths, const float* feats, int C, int64_t* voxels,
                           float* nodes, float* voxel_feats, int64_t* voxel_lengths, int64_t* num_voxels, int B,
-                          int64_t total, float voxel_size, int device, void* stream);
+                          int64_t total, float voxel_size, void* workspace, size_t workspace_bytes, int device,
+                          void* stream);
 
 /* ---- "next" rows: correspondence selectors downstream of pairwise_distance -----------------------
  * v3d_mutual_topk_select_f32 replaces vision3d/ops/mutual_topk_select.py:7-60 (B = 1) and :63-133 (batched):
@@ -263,7 +267,9 @@ int v3d_voxelize_pack_f32(const float* points, const int64_t* lengths, const flo
  * compacted correspondences in torch.nonzero order (ascending batch, row, col): out_batch / out_row / out_col int64 and
  * out_score fp32 (each may be NULL), at most `capacity` entries written, the true count in *num_out (device scalar;
  * k*B*min(N,M) bounds it for mutual selection, k*B*(N+M) otherwise).  The score matrix is read twice, nothing of its
- * size is written unless corr_mat is requested.  No host synchronisation; scratch is stream-ordered (hipMallocAsync).
+ * size is written unless corr_mat is requested.  No host synchronisation.  Scratch (all four selectors): `workspace` of
+ * the matching v3d_*_workspace_bytes() bytes, 256-B aligned, owned by the caller -- or NULL for a stream-ordered
+ * allocation inside (hipMallocAsync / hipFreeAsync on `stream`); a size of 0 means the call needs none.
  *
  * v3d_mutual_select_lists_f32 is the same back end for top-k lists that were never a matrix: row_idx/row_val (B,N,k) =
  * for every row its k best columns, col_idx/col_val (B,M,k) = for every column its k best rows (entries < 0 are
@@ -272,15 +278,17 @@ int v3d_voxelize_pack_f32(const float* points, const int64_t* lengths, const flo
 #define V3D_SEL_LARGEST 1
 #define V3D_SEL_MUTUAL 2
 #define V3D_SEL_THRESHOLD 4
+size_t v3d_mutual_topk_select_workspace_bytes(int B, int N, int M, int k);
+size_t v3d_mutual_select_lists_workspace_bytes(int B, int N, int M, int k);
 int v3d_mutual_topk_select_f32(const float* score, const uint8_t* row_masks, const uint8_t* col_masks, int B, int N,
                                int M, int k, int flags, float threshold, uint8_t* corr_mat, int64_t* out_batch,
                                int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
-                               int device, void* stream);
+                               void* workspace, size_t workspace_bytes, int device, void* stream);
 int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, const int64_t* col_idx,
                                 const float* col_val, const uint8_t* row_masks, const uint8_t* col_masks, int B, int N,
                                 int M, int k, int flags, float threshold, uint8_t* corr_mat, int64_t* out_batch,
                                 int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
-                                int device, void* stream);
+                                void* workspace, size_t workspace_bytes, int device, void* stream);
 
 /* The two other selectors of vision3d/ops/matching.py, on a 2-D score matrix (N,M) fp32.
  * v3d_threshold_select_f32 replaces extract_correspondences_from_scores_threshold (:64-86) after its torch.exp: the cells
@@ -293,15 +301,17 @@ int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, co
  * flat index (torch leaves that open); k > N*M is torch.topk's "selected index k out of range"; with V3D_SEL_DUSTBIN the
  * entries of the last row / last column are dropped AFTER the selection (:110-115), so *num_out <= k (it equals k
  * without the flag; num_out may be NULL then).  Exact radix select (3 histogram passes, +3 only when the k-th value is
- * tied), one compaction pass, sort of the k winners; N*M < 2^32.  No host synchronisation in either; scratch is
- * stream-ordered (hipMallocAsync). */
+ * tied), one compaction pass, sort of the k winners; N*M < 2^32.  No host synchronisation in either; scratch as above
+ * (v3d_threshold_select_workspace_bytes / v3d_global_topk_select_workspace_bytes, or NULL). */
 #define V3D_SEL_DUSTBIN 8
+size_t v3d_threshold_select_workspace_bytes(int64_t N, int64_t M);
+size_t v3d_global_topk_select_workspace_bytes(int64_t N, int64_t M, int64_t k);
 int v3d_threshold_select_f32(const float* score, int64_t N, int64_t M, float threshold, int flags, int64_t* out_row,
-                             int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, int device,
-                             void* stream);
+                             int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, void* workspace,
+                             size_t workspace_bytes, int device, void* stream);
 int v3d_global_topk_select_f32(const float* score, int64_t N, int64_t M, int64_t k, int flags, int64_t* out_row,
-                               int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, int device,
-                               void* stream);
+                               int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, void* workspace,
+                               size_t workspace_bytes, int device, void* stream);
 
 /* ---- "next" rows: PACK-mode row gathers (features row-major (N,C), neighbour table (M,K) int64,
  * entries equal to N -- or anything outside [0,N) -- mean "no neighbour" and read as a row of zeros, which is what the

@@ -999,3 +999,106 @@ def test_knn_interpolate_and_deprecated_spellings(ext):
     sl = torch.tensor([500, 700], device=DEV)
     assert torch.equal(ops.naive_radius_search_pack_mode(q, s, ql, sl, 0.1, 16),
                        ops.radius_search_pack_mode(q, s, ql, sl, 0.1, 16))
+
+
+def test_next_row_entry_points_take_caller_owned_workspaces():
+    """SURVEY 8b ownership contract ("ext never allocates or frees", ops/ball_query.py:38) on the (f) rows, straight through
+    the C ABI: grid subsampling, voxelisation and the four selectors give the same outputs with a caller workspace of
+    v3d_*_workspace_bytes() as with NULL (stream-ordered allocation inside), make no stream-ordered allocation when the
+    workspace is given (the default memory pool's high-water mark stays at zero), and refuse a workspace that is too small."""
+    import ctypes
+
+    from vision3d_amd import _lib
+
+    lib = _lib.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    dev = torch.cuda.current_device()
+    stream = torch.cuda.current_stream().cuda_stream
+    pool = ctypes.c_void_p()
+    assert hip.hipDeviceGetDefaultMemPool(ctypes.byref(pool), dev) == 0
+
+    def pool_mark(reset=False):
+        v = ctypes.c_uint64(0)
+        if reset:
+            assert hip.hipMemPoolSetAttribute(pool, 0x8, ctypes.byref(v)) == 0  # hipMemPoolAttrUsedMemHigh
+        assert hip.hipMemPoolGetAttribute(pool, 0x8, ctypes.byref(v)) == 0
+        return v.value
+
+    def both(nbytes, call, outputs):
+        """call(ws_ptr, ws_bytes) -> rc; outputs() -> list of tensors to compare."""
+        for t in outputs():
+            t.fill_(0)  # rows past the count are not written: the same start for both runs
+        assert call(None, 0) == 0, lib.v3d_last_error_string()
+        torch.cuda.synchronize()
+        want = [t.clone() for t in outputs()]
+        for t in outputs():
+            t.fill_(0)
+        ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=DEV)
+        off = (-ws.data_ptr()) % 256
+        torch.cuda.synchronize()
+        pool_mark(reset=True)
+        assert call(ws.data_ptr() + off, nbytes) == 0, lib.v3d_last_error_string()
+        torch.cuda.synchronize()
+        assert pool_mark() == 0, "a caller workspace was given, yet the call allocated"
+        assert all(torch.equal(a, b) for a, b in zip(outputs(), want))
+        if nbytes > 256:
+            rc = call(ws.data_ptr() + off, nbytes - 256)
+            assert rc != 0 and lib.v3d_error_name(rc).decode() == "V3D_ERR_WORKSPACE"
+            rc = call(ws.data_ptr() + off + 8, nbytes)  # misaligned
+            assert rc != 0 and lib.v3d_error_name(rc).decode() == "V3D_ERR_WORKSPACE"
+
+    g = torch.Generator().manual_seed(77)
+    # grid subsampling + voxelisation
+    lens = torch.tensor([3000, 0, 2000], device=DEV)
+    pts = (torch.rand((5000, 3), generator=g) * 2.0 - 0.5).to(DEV)
+    out, out_l = torch.zeros_like(pts), torch.zeros_like(lens)
+    num = torch.zeros((), dtype=torch.long, device=DEV)
+    both(lib.v3d_grid_subsample_workspace_bytes(3, 5000, 0),
+         lambda p, n: lib.v3d_grid_subsample_pack_f32(pts.data_ptr(), lens.data_ptr(), out.data_ptr(), out_l.data_ptr(),
+                                                      num.data_ptr(), 3, 5000, 0.1, p, n, dev, stream),
+         lambda: [out, out_l, num])
+    feats = torch.randn((5000, 8), generator=g).to(DEV)
+    vox = torch.zeros((5000, 3), dtype=torch.long, device=DEV)
+    vf = torch.zeros_like(feats)
+    both(lib.v3d_grid_subsample_workspace_bytes(3, 5000, 8),
+         lambda p, n: lib.v3d_voxelize_pack_f32(pts.data_ptr(), lens.data_ptr(), feats.data_ptr(), 8, vox.data_ptr(),
+                                                out.data_ptr(), vf.data_ptr(), out_l.data_ptr(), num.data_ptr(), 3, 5000,
+                                                0.1, p, n, dev, stream),
+         lambda: [vox, out, vf, out_l, num])
+    # mutual top-k on a matrix large enough for the sorted back end, and on lists
+    B, N, M, k = 1, 3000, 2500, 3
+    score = torch.randn((B, N, M), generator=g).to(DEV)
+    cap = k * B * min(N, M)
+    ob, orow, ocol = (torch.zeros((cap,), dtype=torch.long, device=DEV) for _ in range(3))
+    osc = torch.zeros((cap,), device=DEV)
+    assert lib.v3d_mutual_topk_select_workspace_bytes(B, N, M, k) > 0
+    both(lib.v3d_mutual_topk_select_workspace_bytes(B, N, M, k),
+         lambda p, n: lib.v3d_mutual_topk_select_f32(score.data_ptr(), None, None, B, N, M, k, 1 | 2, 0.0, None,
+                                                     ob.data_ptr(), orow.data_ptr(), ocol.data_ptr(), osc.data_ptr(),
+                                                     num.data_ptr(), cap, p, n, dev, stream),
+         lambda: [ob, orow, ocol, osc, num])
+    rv, ri = score.topk(k, dim=2)
+    cv, ci = score.topk(k, dim=1)
+    ci, cv = ci.transpose(1, 2).contiguous(), cv.transpose(1, 2).contiguous()
+    ri, rv = ri.contiguous(), rv.contiguous()
+    both(lib.v3d_mutual_select_lists_workspace_bytes(B, N, M, k),
+         lambda p, n: lib.v3d_mutual_select_lists_f32(ri.data_ptr(), rv.data_ptr(), ci.data_ptr(), cv.data_ptr(), None, None,
+                                                      B, N, M, k, 1 | 2, 0.0, None, ob.data_ptr(), orow.data_ptr(),
+                                                      ocol.data_ptr(), osc.data_ptr(), num.data_ptr(), cap, p, n, dev,
+                                                      stream),
+         lambda: [ob, orow, ocol, osc, num])
+    # threshold and global top-k selection
+    mat = score[0].contiguous()
+    cap = 1 << 16
+    orow2, ocol2 = (torch.zeros((cap,), dtype=torch.long, device=DEV) for _ in range(2))
+    osc2 = torch.zeros((cap,), device=DEV)
+    both(lib.v3d_threshold_select_workspace_bytes(N, M),
+         lambda p, n: lib.v3d_threshold_select_f32(mat.data_ptr(), N, M, 3.0, 1, orow2.data_ptr(), ocol2.data_ptr(),
+                                                   osc2.data_ptr(), num.data_ptr(), cap, p, n, dev, stream),
+         lambda: [orow2, ocol2, osc2, num])
+    for kk in (300, 20000):  # sorted in LDS / by the device sort
+        both(lib.v3d_global_topk_select_workspace_bytes(N, M, kk),
+             lambda p, n: lib.v3d_global_topk_select_f32(mat.data_ptr(), N, M, kk, 1, orow2.data_ptr(), ocol2.data_ptr(),
+                                                         osc2.data_ptr(), num.data_ptr(), cap, p, n, dev, stream),
+             lambda: [orow2, ocol2, osc2, num])
+    assert lib.v3d_threshold_select_workspace_bytes(100, 100) == 0  # one-launch size: no scratch at all

@@ -65,9 +65,12 @@ SIGNATURES = {
     "v3d_knn_feat_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64] + _WS + _TAIL),
     "v3d_topk_merge_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_int] + _TAIL),
-    "v3d_grid_subsample_pack_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_f32] + _TAIL),
+    "v3d_grid_subsample_workspace_bytes": (_c_size, [_c_int, _c_i64, _c_int]),
+    "v3d_grid_subsample_pack_f32": (
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_f32] + _WS + _TAIL),
     "v3d_voxelize_pack_f32": (
-        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_f32] + _TAIL),
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_f32] + _WS
+        + _TAIL),
     "v3d_radius_search_workspace_bytes": (_c_size, [_c_int, _c_i64]),
     "v3d_radius_search_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32, _c_int] + _WS + _TAIL),
@@ -76,16 +79,20 @@ SIGNATURES = {
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_int] + _WS + _TAIL),
     "v3d_radius_count_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32] + _WS + _TAIL),
+    "v3d_mutual_topk_select_workspace_bytes": (_c_size, [_c_int, _c_int, _c_int, _c_int]),
+    "v3d_mutual_select_lists_workspace_bytes": (_c_size, [_c_int, _c_int, _c_int, _c_int]),
     "v3d_mutual_topk_select_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
-                 _c_ptr, _c_ptr, _c_i64] + _TAIL),
+                 _c_ptr, _c_ptr, _c_i64] + _WS + _TAIL),
     "v3d_mutual_select_lists_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32, _c_ptr,
-                 _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _TAIL),
+                 _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _WS + _TAIL),
+    "v3d_threshold_select_workspace_bytes": (_c_size, [_c_i64, _c_i64]),
+    "v3d_global_topk_select_workspace_bytes": (_c_size, [_c_i64, _c_i64, _c_i64]),
     "v3d_threshold_select_f32": (
-        _c_int, [_c_ptr, _c_i64, _c_i64, _c_f32, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _TAIL),
+        _c_int, [_c_ptr, _c_i64, _c_i64, _c_f32, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _WS + _TAIL),
     "v3d_global_topk_select_f32": (
-        _c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _TAIL),
+        _c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + _WS + _TAIL),
     "v3d_index_select_rows": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64] + _TAIL),
     "v3d_local_maxpool_pack_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_int] + _TAIL),
     "v3d_knn_interp_weights_pack_f32": (

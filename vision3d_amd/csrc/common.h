@@ -57,6 +57,44 @@ inline int invalid(const char* what, const char* why) {
     }                                                                             \
   } while (0)
 
+// Scratch of an entry point: the caller's workspace (the reference's ownership contract: the extension neither allocates
+// nor frees, e.g. ops/ball_query.py:38 -- checked for size and 256-byte alignment) or, with workspace == NULL, a
+// stream-ordered allocation that release() hands back on the same stream.
+struct Scratch {
+  char* base = nullptr;
+  bool own = false;
+  hipStream_t stream = nullptr;
+  int acquire(const char* what, void* workspace, size_t workspace_bytes, size_t need, hipStream_t s) {
+    stream = s;
+    if (workspace != nullptr) {
+      if (workspace_bytes < need || ((uintptr_t)workspace & 255) != 0) {
+        set_last_error("%s: workspace needs %zu bytes, 256-B aligned (got %zu)", what, need, workspace_bytes);
+        return V3D_ERR_WORKSPACE;
+      }
+      base = static_cast<char*>(workspace);
+      return 0;
+    }
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&base), need ? need : 256, s);
+    if (e != hipSuccess) {
+      set_last_error("%s: hipMallocAsync(%zu): %s", what, need, hipGetErrorString(e));
+      return (int)e;
+    }
+    own = true;
+    return 0;
+  }
+  int release(const char* what, int rc) {
+    if (own) {
+      hipError_t e = hipFreeAsync(base, stream);
+      own = false;
+      if (rc == 0 && e != hipSuccess) {
+        set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
+        rc = (int)e;
+      }
+    }
+    return rc;
+  }
+};
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

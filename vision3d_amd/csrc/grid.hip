@@ -192,10 +192,42 @@ __global__ void gs_lengths_kernel(const unsigned long long* __restrict__ keys, c
 }  // namespace v3d
 
 namespace v3d {
+struct GridLayout {
+  size_t o_off, o_min, o_err, o_k0, o_k1, o_v0, o_v1, o_flag, o_slot, o_head, o_tmp, sort_bytes, scan_bytes, total;
+};
+static int grid_layout(const char* what, int B, int64_t total, int C, GridLayout& g) {
+  const size_t n = (size_t)total;
+  g.sort_bytes = g.scan_bytes = 0;
+  unsigned long long* nullk = nullptr;
+  int* nulli = nullptr;
+  const unsigned end_bit = 3 * kGsCoordBits + 10;
+  V3D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, g.sort_bytes, nullk, nullk, nulli, nulli, n, 0, end_bit, nullptr), what);
+  V3D_HIP_TRY(rocprim::exclusive_scan(nullptr, g.scan_bytes, nulli, nulli, 0, n, rocprim::plus<int>(), nullptr), what);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += align_up(bytes, 256);
+    return at;
+  };
+  g.o_off = take(sizeof(long long) * ((size_t)B + 1));
+  g.o_min = take(sizeof(int) * 3 * (size_t)B);
+  g.o_err = take(sizeof(int));
+  g.o_k0 = take(8 * n);
+  g.o_k1 = take(8 * n);
+  g.o_v0 = take(4 * n);
+  g.o_v1 = take(4 * n);
+  g.o_flag = take(4 * n);
+  g.o_slot = take(4 * n);
+  g.o_head = take(C > 0 ? 4 * n : 0);
+  g.o_tmp = take(std::max(g.sort_bytes, g.scan_bytes));
+  g.total = off;
+  return 0;
+}
+
 static int grid_reduce(const char* what, const float* points, const int64_t* lengths, const float* feats, int C,
                        float* sampled_points, int64_t* out_voxels, float* out_feats, int64_t* sampled_lengths,
-                       int64_t* num_sampled, int B, int64_t total, float voxel_size, bool divide, int device,
-                       void* stream_) {
+                       int64_t* num_sampled, int B, int64_t total, float voxel_size, bool divide, void* workspace,
+                       size_t workspace_bytes, int device, void* stream_) {
   V3D_REQUIRE(B >= 0 && total >= 0, what, "negative dimension");
   V3D_REQUIRE(voxel_size > 0.f, what, "voxel_size must be positive");  // NaN fails too
   V3D_REQUIRE(num_sampled && (B == 0 || (lengths && sampled_lengths)) && (total == 0 || (points && sampled_points)),
@@ -214,25 +246,16 @@ static int grid_reduce(const char* what, const float* points, const int64_t* len
   // :64: 1 / voxel_size is a Python float, rounded to float32 by the product; voxelize.py:22 divides instead
   const float inv = divide ? -voxel_size : (float)(1.0 / (double)voxel_size);
 
+  GridLayout g;
+  if (int rc = grid_layout(what, B, total, C, g)) return rc;
   const size_t n = (size_t)total;
-  size_t sort_bytes = 0, scan_bytes = 0;
-  unsigned long long* nullk = nullptr;
-  int* nulli = nullptr;
+  size_t sort_bytes = g.sort_bytes, scan_bytes = g.scan_bytes;
   const unsigned end_bit = 3 * kGsCoordBits + 10;
-  V3D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, nullk, nullk, nulli, nulli, n, 0, end_bit, stream), what);
-  V3D_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, nulli, nulli, 0, n, rocprim::plus<int>(), stream), what);
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    const size_t at = off;
-    off += align_up(bytes, 256);
-    return at;
-  };
-  const size_t o_off = take(sizeof(long long) * ((size_t)B + 1)), o_min = take(sizeof(int) * 3 * (size_t)B),
-               o_err = take(sizeof(int)), o_k0 = take(8 * n), o_k1 = take(8 * n), o_v0 = take(4 * n), o_v1 = take(4 * n),
-               o_flag = take(4 * n), o_slot = take(4 * n), o_head = take(C > 0 ? 4 * n : 0),
-               o_tmp = take(std::max(sort_bytes, scan_bytes));
-  char* base = nullptr;
-  V3D_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), off, stream), what);
+  const size_t o_off = g.o_off, o_min = g.o_min, o_err = g.o_err, o_k0 = g.o_k0, o_k1 = g.o_k1, o_v0 = g.o_v0,
+               o_v1 = g.o_v1, o_flag = g.o_flag, o_slot = g.o_slot, o_head = g.o_head, o_tmp = g.o_tmp;
+  Scratch scratch;
+  if (int rc = scratch.acquire(what, workspace, workspace_bytes, g.total, stream)) return rc;
+  char* base = scratch.base;
   long long* offsets = reinterpret_cast<long long*>(base + o_off);
   int* minv = reinterpret_cast<int*>(base + o_min);
   int* error = reinterpret_cast<int*>(base + o_err);
@@ -280,27 +303,30 @@ static int grid_reduce(const char* what, const float* points, const int64_t* len
                        sampled_lengths, B, (long long)total);
     rc = launch_status(what);
   } while (0);
-  hipError_t e = hipFreeAsync(base, stream);
-  if (rc == 0 && e != hipSuccess) {
-    set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
-    rc = (int)e;
-  }
-  return rc;
+  return scratch.release(what, rc);
 }
 }  // namespace v3d
 
 extern "C" {
 
+size_t v3d_grid_subsample_workspace_bytes(int B, int64_t total, int C) {
+  if (B <= 0 || total <= 0 || C < 0 || B > v3d::kGsMaxClouds || total >= (int64_t)INT32_MAX) return 0;
+  v3d::GridLayout g;
+  return v3d::grid_layout("grid_subsample_workspace_bytes", B, total, C, g) == 0 ? g.total : 0;
+}
+
 int v3d_grid_subsample_pack_f32(const float* points, const int64_t* lengths, float* sampled_points,
                                 int64_t* sampled_lengths, int64_t* num_sampled, int B, int64_t total, float voxel_size,
-                                int device, void* stream) {
+                                void* workspace, size_t workspace_bytes, int device, void* stream) {
   return v3d::grid_reduce("grid_subsample_pack_mode", points, lengths, nullptr, 0, sampled_points, nullptr, nullptr,
-                          sampled_lengths, num_sampled, B, total, voxel_size, false, device, stream);
+                          sampled_lengths, num_sampled, B, total, voxel_size, false, workspace, workspace_bytes, device,
+                          stream);
 }
 
 int v3d_voxelize_pack_f32(const float* points, const int64_t* lengths, const float* feats, int C, int64_t* voxels,
                           float* nodes, float* voxel_feats, int64_t* voxel_lengths, int64_t* num_voxels, int B,
-                          int64_t total, float voxel_size, int device, void* stream) {
+                          int64_t total, float voxel_size, void* workspace, size_t workspace_bytes, int device,
+                          void* stream) {
   using namespace v3d;
   const char* what = "voxelize_pack_mode";
   V3D_REQUIRE(total <= 0 || voxels, what, "null pointer");
@@ -309,7 +335,7 @@ int v3d_voxelize_pack_f32(const float* points, const int64_t* lengths, const flo
     return V3D_ERR_SIZE_LIMIT;
   }
   return grid_reduce(what, points, lengths, feats, C, nodes, voxels, voxel_feats, voxel_lengths, num_voxels, B, total,
-                     voxel_size, true, device, stream);
+                     voxel_size, true, workspace, workspace_bytes, device, stream);
 }
 
 }  // extern "C"

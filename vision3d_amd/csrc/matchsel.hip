@@ -559,13 +559,88 @@ __global__ __launch_bounds__(256) void ms_emit_sorted_kernel(const unsigned long
 
 static inline int ms_vec_ok(const float* score) { return ((uintptr_t)score & 15) == 0 ? 1 : 0; }
 
+struct ThrLayout {
+  size_t o_slots, o_tmp, scan_bytes, total;
+};
+static int thr_layout(int64_t tiles, ThrLayout& t) {
+  t.scan_bytes = 0;
+  int* ni = nullptr;
+  hipError_t e = rocprim::exclusive_scan(nullptr, t.scan_bytes, ni, ni, 0, (size_t)tiles, rocprim::plus<int>(), nullptr);
+  if (e != hipSuccess) return (int)e;
+  t.o_slots = align_up(4 * (size_t)tiles, 256);
+  t.o_tmp = 2 * t.o_slots;
+  t.total = t.o_tmp + align_up(t.scan_bytes, 256);
+  return 0;
+}
+
+// scratch of v3d_global_topk_select_f32 and the short-list parameters (see the entry point)
+struct GtkLayout {
+  bool small_sort;
+  unsigned rank, list_cap;
+  size_t sort_bytes, scan_bytes, o_state, o_hist, zero_bytes, o_cand, o_list, o_sorted, o_keep, o_slot, o_tmp, total;
+};
+static int gtk_layout(int64_t total, int64_t k, GtkLayout& g) {
+  g.small_sort = k <= kMsSortSmall;
+  g.sort_bytes = g.scan_bytes = 0;
+  if (!g.small_sort) {
+    unsigned long long* nk = nullptr;
+    int* ni = nullptr;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, g.sort_bytes, nk, nk, (size_t)k, 0, 64, nullptr);
+    if (e == hipSuccess)
+      e = rocprim::exclusive_scan(nullptr, g.scan_bytes, ni, ni, 0, (size_t)k, rocprim::plus<int>(), nullptr);
+    if (e != hipSuccess) return (int)e;
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += align_up(bytes, 256);
+    return at;
+  };
+  g.o_state = take(sizeof(MsState));
+  g.o_hist = take(6 * kMsBins * sizeof(unsigned));
+  g.zero_bytes = off;
+  // Short-list route (k a small fraction of the matrix): rank of the pivot in the 8192-cell sample = expected number of
+  // sampled cells among the k best, plus six standard deviations, plus 16; the list holds three times the expected
+  // number of cells under the pivot.  Whatever the data does (ties, adversarial layouts), a list that overflows or holds
+  // fewer than k cells is ignored and the selection reads the matrix: the route changes the speed, never the result.
+  g.rank = g.list_cap = 0;
+  if (total >= (int64_t)kMsSamples * 128) {
+    const double expect = (double)kMsSamples * (double)k / (double)total;
+    const double r = std::ceil(expect + 6.0 * std::sqrt(expect) + 16.0);
+    const double cap = 3.0 * r * (double)total / kMsSamples + 4096.0;
+    if (r <= kMsSamples / 24 && cap <= (double)total / 8) {
+      g.rank = (unsigned)r;
+      g.list_cap = (unsigned)cap;
+    }
+  }
+  g.o_cand = take(8 * (size_t)k);
+  g.o_list = take(8 * (size_t)g.list_cap);
+  g.o_sorted = g.small_sort ? 0 : take(8 * (size_t)k);
+  g.o_keep = g.small_sort ? 0 : take(4 * (size_t)k);
+  g.o_slot = g.small_sort ? 0 : take(4 * (size_t)k);
+  g.o_tmp = g.small_sort ? 0 : take(std::max(g.sort_bytes, g.scan_bytes));
+  g.total = off;
+  return 0;
+}
+
 }  // namespace v3d
 
 extern "C" {
 
+size_t v3d_threshold_select_workspace_bytes(int64_t N, int64_t M) {
+  if (N <= 0 || M <= 0 || N * M <= v3d::kMsSmallCells) return 0;
+  v3d::ThrLayout t;
+  return v3d::thr_layout(v3d::ceil_div(N * M, v3d::kMsTile), t) == 0 ? t.total : 0;
+}
+size_t v3d_global_topk_select_workspace_bytes(int64_t N, int64_t M, int64_t k) {
+  if (N <= 0 || M <= 0 || k <= 0 || k > N * M) return 0;
+  v3d::GtkLayout g;
+  return v3d::gtk_layout(N * M, k, g) == 0 ? g.total : 0;
+}
+
 int v3d_threshold_select_f32(const float* score, int64_t N, int64_t M, float threshold, int flags, int64_t* out_row,
-                             int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, int device,
-                             void* stream_) {
+                             int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, void* workspace,
+                             size_t workspace_bytes, int device, void* stream_) {
   using namespace v3d;
   const char* what = "threshold_select";
   V3D_REQUIRE(N >= 0 && M >= 0 && capacity >= 0, what, "negative dimension");
@@ -591,16 +666,17 @@ int v3d_threshold_select_f32(const float* score, int64_t N, int64_t M, float thr
                        vec, out_row, out_col, out_score, num_out, capacity);
     return launch_status(what);
   }
-  size_t scan_bytes = 0;
-  int* ni = nullptr;
-  hipError_t e = rocprim::exclusive_scan(nullptr, scan_bytes, ni, ni, 0, (size_t)tiles, rocprim::plus<int>(), stream);
-  if (e != hipSuccess) {
+  ThrLayout tl;
+  if (thr_layout(tiles, tl) != 0) {
     set_last_error("%s: rocPRIM size query failed", what);
-    return (int)e;
+    return (int)hipErrorUnknown;
   }
-  const size_t o_slots = align_up(4 * (size_t)tiles, 256), o_tmp = 2 * o_slots;
-  char* base = nullptr;
-  V3D_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), o_tmp + align_up(scan_bytes, 256), stream), what);
+  size_t scan_bytes = tl.scan_bytes;
+  const size_t o_slots = tl.o_slots, o_tmp = tl.o_tmp;
+  Scratch scratch;
+  if (int rc0 = scratch.acquire(what, workspace, workspace_bytes, tl.total, stream)) return rc0;
+  char* base = scratch.base;
+  hipError_t e;
   int* counts = reinterpret_cast<int*>(base);
   int* slots = reinterpret_cast<int*>(base + o_slots);
   hipLaunchKernelGGL(ms_thr_count_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, score, total, threshold, largest, vec,
@@ -615,17 +691,12 @@ int v3d_threshold_select_f32(const float* score, int64_t N, int64_t M, float thr
                        largest, vec, counts, slots, out_row, out_col, out_score, num_out, capacity);
     rc = launch_status(what);
   }
-  e = hipFreeAsync(base, stream);
-  if (rc == 0 && e != hipSuccess) {
-    set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
-    rc = (int)e;
-  }
-  return rc;
+  return scratch.release(what, rc);
 }
 
 int v3d_global_topk_select_f32(const float* score, int64_t N, int64_t M, int64_t k, int flags, int64_t* out_row,
-                               int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, int device,
-                               void* stream_) {
+                               int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity, void* workspace,
+                               size_t workspace_bytes, int device, void* stream_) {
   using namespace v3d;
   const char* what = "global_topk_select";
   V3D_REQUIRE(N >= 0 && M >= 0 && k >= 0 && capacity >= 0, what, "negative dimension");
@@ -646,48 +717,19 @@ int v3d_global_topk_select_f32(const float* score, int64_t N, int64_t M, int64_t
   V3D_REQUIRE(score, what, "null pointer");
   const int largest = (flags & V3D_SEL_LARGEST) ? 1 : 0, dustbin = (flags & V3D_SEL_DUSTBIN) ? 1 : 0;
   const int vec = ms_vec_ok(score);
-  const bool small_sort = k <= kMsSortSmall;
-
-  size_t sort_bytes = 0, scan_bytes = 0;
-  if (!small_sort) {
-    unsigned long long* nk = nullptr;
-    int* ni = nullptr;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_bytes, nk, nk, (size_t)k, 0, 64, stream);
-    if (e == hipSuccess)
-      e = rocprim::exclusive_scan(nullptr, scan_bytes, ni, ni, 0, (size_t)k, rocprim::plus<int>(), stream);
-    if (e != hipSuccess) {
-      set_last_error("%s: rocPRIM size query failed", what);
-      return (int)e;
-    }
+  GtkLayout gl;
+  if (gtk_layout(total, k, gl) != 0) {
+    set_last_error("%s: rocPRIM size query failed", what);
+    return (int)hipErrorUnknown;
   }
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    const size_t at = off;
-    off += align_up(bytes, 256);
-    return at;
-  };
-  const size_t o_state = take(sizeof(MsState)), o_hist = take(6 * kMsBins * sizeof(unsigned));
-  const size_t zero_bytes = off;
-  // Short-list route (k a small fraction of the matrix): rank of the pivot in the 8192-cell sample = expected number of
-  // sampled cells among the k best, plus six standard deviations, plus 16; the list holds three times the expected
-  // number of cells under the pivot.  Whatever the data does (ties, adversarial layouts), a list that overflows or holds
-  // fewer than k cells is ignored and the selection reads the matrix: the route changes the speed, never the result.
-  unsigned rank = 0, list_cap = 0;
-  if (total >= (int64_t)kMsSamples * 128) {
-    const double expect = (double)kMsSamples * (double)k / (double)total;
-    const double r = std::ceil(expect + 6.0 * std::sqrt(expect) + 16.0);
-    const double cap = 3.0 * r * (double)total / kMsSamples + 4096.0;
-    if (r <= kMsSamples / 24 && cap <= (double)total / 8) {
-      rank = (unsigned)r;
-      list_cap = (unsigned)cap;
-    }
-  }
-  const size_t o_cand = take(8 * (size_t)k);
-  const size_t o_list = take(8 * (size_t)list_cap);
-  const size_t o_sorted = small_sort ? 0 : take(8 * (size_t)k), o_keep = small_sort ? 0 : take(4 * (size_t)k),
-               o_slot = small_sort ? 0 : take(4 * (size_t)k), o_tmp = small_sort ? 0 : take(std::max(sort_bytes, scan_bytes));
-  char* base = nullptr;
-  V3D_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), off, stream), what);
+  const bool small_sort = gl.small_sort;
+  size_t sort_bytes = gl.sort_bytes, scan_bytes = gl.scan_bytes;
+  const unsigned rank = gl.rank, list_cap = gl.list_cap;
+  const size_t o_state = gl.o_state, o_hist = gl.o_hist, zero_bytes = gl.zero_bytes, o_cand = gl.o_cand, o_list = gl.o_list,
+               o_sorted = gl.o_sorted, o_keep = gl.o_keep, o_slot = gl.o_slot, o_tmp = gl.o_tmp;
+  Scratch scratch;
+  if (int rc0 = scratch.acquire(what, workspace, workspace_bytes, gl.total, stream)) return rc0;
+  char* base = scratch.base;
   int rc = 0;
   hipError_t e = hipMemsetAsync(base, 0, zero_bytes, stream);
   if (e != hipSuccess) {
@@ -734,12 +776,7 @@ int v3d_global_topk_select_f32(const float* score, int64_t N, int64_t M, int64_t
       }
     }
   }
-  e = hipFreeAsync(base, stream);
-  if (rc == 0 && e != hipSuccess) {
-    set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
-    rc = (int)e;
-  }
-  return rc;
+  return scratch.release(what, rc);
 }
 
 }  // extern "C"

@@ -642,14 +642,54 @@ static int select_prologue(const char* what, int B, int N, int M, int k, const S
   return 0;
 }
 
+// scratch of v3d_mutual_topk_select_f32: row / column lists, partial column lists of the row splits, the back end's buffers
+struct MutualLayout {
+  int col_tiles, S, rows_per_split;
+  size_t o_ri, o_rv, o_ci, o_cv, o_pk, o_pi;
+  SelectSizes z;
+};
+static int mutual_layout(int B, int N, int M, int k, MutualLayout& m) {
+  // row ranges for the column side: enough workgroups to fill 256 CUs, at least 256 rows each
+  m.col_tiles = (int)ceil_div(M, kColTile);
+  int S = (int)ceil_div(1024, std::max<int64_t>(1, (int64_t)B * m.col_tiles));
+  S = std::max(1, std::min({S, (int)ceil_div(N, 256), 64}));
+  m.rows_per_split = (int)(ceil_div(ceil_div(N, S), kColTile) * kColTile);
+  m.S = (int)ceil_div(N, m.rows_per_split);
+  const size_t nR = (size_t)B * N * k, nC = (size_t)B * M * k;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += align_up(bytes, 256);
+    return at;
+  };
+  m.o_ri = take(4 * nR);
+  m.o_rv = take(4 * nR);
+  m.o_ci = take(4 * nC);
+  m.o_cv = take(4 * nC);
+  m.o_pk = take(4 * nC * m.S);
+  m.o_pi = take(4 * nC * m.S);
+  return select_sizes(B, N, M, k, off, m.z, nullptr);
+}
+
 }  // namespace v3d
 
 extern "C" {
 
+size_t v3d_mutual_topk_select_workspace_bytes(int B, int N, int M, int k) {
+  if (B <= 0 || N <= 0 || M <= 0 || k <= 0) return 0;
+  v3d::MutualLayout m;
+  return v3d::mutual_layout(B, N, M, k, m) == 0 ? m.z.total : 0;
+}
+size_t v3d_mutual_select_lists_workspace_bytes(int B, int N, int M, int k) {
+  if (B <= 0 || N <= 0 || M <= 0 || k <= 0 || v3d::select_is_small(B, N, M, k)) return 0;
+  v3d::SelectSizes z;
+  return v3d::select_sizes(B, N, M, k, 0, z, nullptr) == 0 ? z.total : 0;
+}
+
 int v3d_mutual_topk_select_f32(const float* score, const uint8_t* row_masks, const uint8_t* col_masks, int B, int N,
                                int M, int k, int flags, float threshold, uint8_t* corr_mat, int64_t* out_batch,
                                int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
-                               int device, void* stream_) {
+                               void* workspace, size_t workspace_bytes, int device, void* stream_) {
   using namespace v3d;
   const char* what = "mutual_topk_select";
   V3D_REQUIRE(B >= 0 && N >= 0 && M >= 0 && k >= 0 && capacity >= 0, what, "negative dimension");
@@ -670,30 +710,18 @@ int v3d_mutual_topk_select_f32(const float* score, const uint8_t* row_masks, con
   if (rc || done) return rc;
   V3D_REQUIRE(score, what, "null pointer");
 
-  // row ranges for the column side: enough workgroups to fill 256 CUs, at least 256 rows each
-  const int col_tiles = (int)ceil_div(M, kColTile);
-  int S = (int)ceil_div(1024, (int64_t)B * col_tiles);
-  S = std::max(1, std::min({S, (int)ceil_div(N, 256), 64}));
-  const int rows_per_split = (int)(ceil_div(ceil_div(N, S), kColTile) * kColTile);
-  S = (int)ceil_div(N, rows_per_split);
-
-  const size_t nR = (size_t)B * N * k, nC = (size_t)B * M * k;
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    const size_t at = off;
-    off += align_up(bytes, 256);
-    return at;
-  };
-  const size_t o_ri = take(4 * nR), o_rv = take(4 * nR), o_ci = take(4 * nC), o_cv = take(4 * nC),
-               o_pk = take(4 * nC * S), o_pi = take(4 * nC * S);
-  SelectSizes z;
-  rc = select_sizes(B, N, M, k, off, z, stream);
+  MutualLayout ml;
+  rc = mutual_layout(B, N, M, k, ml);
   if (rc) {
     set_last_error("%s: rocPRIM size query failed", what);
     return rc;
   }
-  char* base = nullptr;
-  V3D_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), z.total, stream), what);
+  const int col_tiles = ml.col_tiles, S = ml.S, rows_per_split = ml.rows_per_split;
+  const size_t o_ri = ml.o_ri, o_rv = ml.o_rv, o_ci = ml.o_ci, o_cv = ml.o_cv, o_pk = ml.o_pk, o_pi = ml.o_pi;
+  const SelectSizes& z = ml.z;
+  Scratch scratch;
+  if ((rc = scratch.acquire(what, workspace, workspace_bytes, z.total, stream)) != 0) return rc;
+  char* base = scratch.base;
   int* row_i = reinterpret_cast<int*>(base + o_ri);
   float* row_v = reinterpret_cast<float*>(base + o_rv);
   int* col_i = reinterpret_cast<int*>(base + o_ci);
@@ -725,19 +753,14 @@ int v3d_mutual_topk_select_f32(const float* score, const uint8_t* row_masks, con
       rc = select_from_lists<int>(row_i, row_v, col_i, col_v, row_masks, col_masks, B, N, M, k, flags, threshold, o, base,
                                   z, stream, what);
   }
-  hipError_t e = hipFreeAsync(base, stream);
-  if (rc == 0 && e != hipSuccess) {
-    set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
-    rc = (int)e;
-  }
-  return rc;
+  return scratch.release(what, rc);
 }
 
 int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, const int64_t* col_idx,
                                 const float* col_val, const uint8_t* row_masks, const uint8_t* col_masks, int B, int N,
                                 int M, int k, int flags, float threshold, uint8_t* corr_mat, int64_t* out_batch,
                                 int64_t* out_row, int64_t* out_col, float* out_score, int64_t* num_out, int64_t capacity,
-                                int device, void* stream_) {
+                                void* workspace, size_t workspace_bytes, int device, void* stream_) {
   using namespace v3d;
   const char* what = "mutual_select_lists";
   V3D_REQUIRE(B >= 0 && N >= 0 && M >= 0 && k >= 0 && capacity >= 0, what, "negative dimension");
@@ -765,16 +788,11 @@ int v3d_mutual_select_lists_f32(const int64_t* row_idx, const float* row_val, co
     set_last_error("%s: rocPRIM size query failed", what);
     return rc;
   }
-  char* base = nullptr;
-  V3D_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), z.total, stream), what);
+  Scratch scratch;
+  if ((rc = scratch.acquire(what, workspace, workspace_bytes, z.total, stream)) != 0) return rc;
   rc = select_from_lists<int64_t>(row_idx, row_val, col_idx, col_val, row_masks, col_masks, B, N, M, k, flags, threshold,
-                                  o, base, z, stream, what);
-  hipError_t e = hipFreeAsync(base, stream);
-  if (rc == 0 && e != hipSuccess) {
-    set_last_error("%s: hipFreeAsync: %s", what, hipGetErrorString(e));
-    rc = (int)e;
-  }
-  return rc;
+                                  o, scratch.base, z, stream, what);
+  return scratch.release(what, rc);
 }
 
 }  // extern "C"

@@ -110,6 +110,16 @@ def _workspace(nbytes, like):
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=like.device)
 
 
+def _ws_args(nbytes, like):
+    """(tensor kept alive by the caller, pointer, size) of a torch-owned workspace; a call that needs no scratch gets
+    (None, NULL, 0).  torch's allocations are 512-byte aligned, which covers the ABI's 256."""
+    nbytes = int(nbytes)
+    if nbytes == 0:
+        return None, None, 0
+    ws = _workspace(nbytes, like)
+    return ws, ws.data_ptr(), ws.numel()
+
+
 # --------------------------------------------------------------------------------------------------------
 def ball_query_multi(q_points, s_points, indices_list, max_radii, num_samples_list):
     """Multi-scale ball query (PointNet++ MSG): up to four (radius, k) scales over the same clouds in one pass; every
@@ -518,9 +528,10 @@ def grid_subsample_pack(points, lengths, sampled_points, sampled_lengths, num_sa
     if sampled_points.shape[0] < points.shape[0] or sampled_lengths.shape[0] != lengths.shape[0]:
         raise RuntimeError("grid_subsample_pack: output buffers too small")
     dev, stream = _where(points)
+    ws, wp, wn = _ws_args(_lib.lib().v3d_grid_subsample_workspace_bytes(lengths.shape[0], points.shape[0], 0), points)
     rc = _lib.lib().v3d_grid_subsample_pack_f32(
         points.data_ptr(), lengths.data_ptr(), sampled_points.data_ptr(), sampled_lengths.data_ptr(),
-        num_sampled.data_ptr(), lengths.shape[0], points.shape[0], float(voxel_size), dev, stream)
+        num_sampled.data_ptr(), lengths.shape[0], points.shape[0], float(voxel_size), wp, wn, dev, stream)
     _lib.check(rc, "grid_subsample_pack_mode")
 
 
@@ -550,10 +561,11 @@ def voxelize_pack(points, lengths, voxels, nodes, voxel_lengths, num_voxels, vox
         if feats.shape[0] != n or voxel_feats.shape[0] < n or voxel_feats.shape[1] != C:
             raise RuntimeError("voxelize_pack: feats (N,C) / voxel_feats (N,C) do not match the points")
     dev, stream = _where(points)
+    ws, wp, wn = _ws_args(_lib.lib().v3d_grid_subsample_workspace_bytes(lengths.shape[0], n, C), points)
     rc = _lib.lib().v3d_voxelize_pack_f32(
         points.data_ptr(), lengths.data_ptr(), _ptr(feats) if C else None, C, voxels.data_ptr(), nodes.data_ptr(),
         _ptr(voxel_feats) if C else None, voxel_lengths.data_ptr(), num_voxels.data_ptr(), lengths.shape[0], n,
-        float(voxel_size), dev, stream)
+        float(voxel_size), wp, wn, dev, stream)
     _lib.check(rc, "voxelize_pack_mode")
 
 
@@ -614,10 +626,11 @@ def mutual_topk_select(score_mat, k, corr_mat=None, out_batch=None, out_row=None
     capacity = _select_outputs("mutual_topk_select", corr_mat, out_batch, out_row, out_col, out_score, num_out,
                                (B, N, M))
     dev, stream = _where(score_mat)
+    ws, wp, wn = _ws_args(_lib.lib().v3d_mutual_topk_select_workspace_bytes(B, N, M, int(k)), score_mat)
     rc = _lib.lib().v3d_mutual_topk_select_f32(
         score_mat.data_ptr(), _ptr(row_masks), _ptr(col_masks), B, N, M, int(k),
         _select_flags(largest, mutual, threshold), float(threshold if threshold is not None else 0.0), _ptr(corr_mat),
-        _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev, stream)
+        _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, wp, wn, dev, stream)
     _lib.check(rc, "mutual_topk_select")
 
 
@@ -643,11 +656,12 @@ def mutual_select_lists(row_idx, row_val, col_idx, col_val, num_cols_total, corr
     capacity = _select_outputs("mutual_select_lists", corr_mat, out_batch, out_row, out_col, out_score, num_out,
                                (B, N, M))
     dev, stream = _where(row_idx)
+    ws, wp, wn = _ws_args(_lib.lib().v3d_mutual_select_lists_workspace_bytes(B, N, M, int(k)), row_idx)
     rc = _lib.lib().v3d_mutual_select_lists_f32(
         row_idx.data_ptr(), _ptr(row_val), col_idx.data_ptr(), _ptr(col_val), _ptr(row_masks), _ptr(col_masks), B, N, M,
         k, _select_flags(largest, mutual, threshold), float(threshold if threshold is not None else 0.0),
-        _ptr(corr_mat), _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev,
-        stream)
+        _ptr(corr_mat), _ptr(out_batch), _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, wp, wn,
+        dev, stream)
     _lib.check(rc, "mutual_select_lists")
 
 
@@ -667,9 +681,10 @@ def threshold_select(score_mat, threshold, out_row=None, out_col=None, out_score
     capacity = _matrix_select_outputs(out_row, out_col, out_score, num_out)
     N, M = score_mat.shape
     dev, stream = _where(score_mat)
+    ws, wp, wn = _ws_args(_lib.lib().v3d_threshold_select_workspace_bytes(N, M), score_mat)
     rc = _lib.lib().v3d_threshold_select_f32(
         score_mat.data_ptr(), N, M, float(threshold), SEL_LARGEST if largest else 0, _ptr(out_row), _ptr(out_col),
-        _ptr(out_score), _ptr(num_out), capacity, dev, stream)
+        _ptr(out_score), _ptr(num_out), capacity, wp, wn, dev, stream)
     _lib.check(rc, "threshold_select")
 
 
@@ -685,9 +700,10 @@ def global_topk_select(score_mat, k, out_row=None, out_col=None, out_score=None,
     capacity = _matrix_select_outputs(out_row, out_col, out_score, num_out)
     N, M = score_mat.shape
     dev, stream = _where(score_mat)
+    ws, wp, wn = _ws_args(_lib.lib().v3d_global_topk_select_workspace_bytes(N, M, int(k)), score_mat)
     rc = _lib.lib().v3d_global_topk_select_f32(
         score_mat.data_ptr(), N, M, int(k), (SEL_LARGEST if largest else 0) | (SEL_DUSTBIN if has_dustbin else 0),
-        _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, dev, stream)
+        _ptr(out_row), _ptr(out_col), _ptr(out_score), _ptr(num_out), capacity, wp, wn, dev, stream)
     _lib.check(rc, "global_topk_select")
 
 
