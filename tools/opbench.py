@@ -13,7 +13,14 @@ from vision3d_amd import ext  # noqa: E402
 DEV = "cuda:0"
 
 
+BATCH = int(os.environ.get("OPBENCH_BATCH", "10"))
+
+
 def timeit(fn, iters=30, warm=5):
+    """Median / minimum time per call over `iters` samples; a sample = BATCH back-to-back calls between one event pair.
+    (r01/r02 timed ONE call per pair: an event pair around a single launch also measures the ~4-5 us between the
+    dispatch of the start marker and the kernel's first wave, which is a quarter of a 20 us kernel -- rocprofv3's kernel
+    trace of `three_interp_fwd` reads 19.5 us where the single-call pair read 24-25.  OPBENCH_BATCH=1 restores that.)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -21,10 +28,11 @@ def timeit(fn, iters=30, warm=5):
     for _ in range(iters):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        fn()
+        for _ in range(BATCH):
+            fn()
         e.record()
         torch.cuda.synchronize()
-        ts.append(s.elapsed_time(e))
+        ts.append(s.elapsed_time(e) / BATCH)
     return float(np.median(ts)), float(np.min(ts))
 
 
