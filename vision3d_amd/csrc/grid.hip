@@ -35,9 +35,16 @@ __device__ __forceinline__ int gs_voxel(float p, float scale) {
 
 constexpr int kGsMinSplit = 16;  // workgroups per cloud in the minimum-voxel pass
 
-__global__ void gs_minvox_init_kernel(int* __restrict__ minv, int B) {
+// one launch for every small initialisation of a call: minimum voxels, the error flag, the per-cloud counts, the total
+__global__ void gs_init_kernel(int* __restrict__ minv, int* __restrict__ error, int64_t* __restrict__ out_len,
+                               int64_t* __restrict__ num_out, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * 3) minv[i] = INT32_MAX;
+  if (i < B) out_len[i] = 0;
+  if (i == 0) {
+    *error = 0;
+    *num_out = 0;
+  }
 }
 
 // kGsMinSplit workgroups per cloud: its first point and its minimum voxel (grid_subsample.py:75), combined with
@@ -195,12 +202,19 @@ namespace v3d {
 struct GridLayout {
   size_t o_off, o_min, o_err, o_k0, o_k1, o_v0, o_v1, o_flag, o_slot, o_head, o_tmp, sort_bytes, scan_bytes, total;
 };
+// the sort only has to look at the key bits that can differ: 3 x 18 coordinate bits + the bits of the largest cloud number
+static unsigned grid_end_bit(int B) {
+  unsigned cloud_bits = 1;
+  while (((unsigned)(B - 1) >> cloud_bits) != 0) ++cloud_bits;
+  return 3 * kGsCoordBits + cloud_bits;
+}
+
 static int grid_layout(const char* what, int B, int64_t total, int C, GridLayout& g) {
   const size_t n = (size_t)total;
   g.sort_bytes = g.scan_bytes = 0;
   unsigned long long* nullk = nullptr;
   int* nulli = nullptr;
-  const unsigned end_bit = 3 * kGsCoordBits + 10;
+  const unsigned end_bit = grid_end_bit(B);
   V3D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, g.sort_bytes, nullk, nullk, nulli, nulli, n, 0, end_bit, nullptr), what);
   V3D_HIP_TRY(rocprim::exclusive_scan(nullptr, g.scan_bytes, nulli, nulli, 0, n, rocprim::plus<int>(), nullptr), what);
   size_t off = 0;
@@ -240,9 +254,11 @@ static int grid_reduce(const char* what, const float* points, const int64_t* len
   DeviceGuard guard(device);
   if (guard.rc) return guard.rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (B > 0) V3D_HIP_TRY(hipMemsetAsync(sampled_lengths, 0, sizeof(int64_t) * (size_t)B, stream), what);
-  V3D_HIP_TRY(hipMemsetAsync(num_sampled, 0, sizeof(int64_t), stream), what);
-  if (total == 0 || B == 0) return 0;
+  if (total == 0 || B == 0) {
+    if (B > 0) V3D_HIP_TRY(hipMemsetAsync(sampled_lengths, 0, sizeof(int64_t) * (size_t)B, stream), what);
+    V3D_HIP_TRY(hipMemsetAsync(num_sampled, 0, sizeof(int64_t), stream), what);
+    return 0;
+  }
   // :64: 1 / voxel_size is a Python float, rounded to float32 by the product; voxelize.py:22 divides instead
   const float inv = divide ? -voxel_size : (float)(1.0 / (double)voxel_size);
 
@@ -250,7 +266,7 @@ static int grid_reduce(const char* what, const float* points, const int64_t* len
   if (int rc = grid_layout(what, B, total, C, g)) return rc;
   const size_t n = (size_t)total;
   size_t sort_bytes = g.sort_bytes, scan_bytes = g.scan_bytes;
-  const unsigned end_bit = 3 * kGsCoordBits + 10;
+  const unsigned end_bit = grid_end_bit(B);
   const size_t o_off = g.o_off, o_min = g.o_min, o_err = g.o_err, o_k0 = g.o_k0, o_k1 = g.o_k1, o_v0 = g.o_v0,
                o_v1 = g.o_v1, o_flag = g.o_flag, o_slot = g.o_slot, o_head = g.o_head, o_tmp = g.o_tmp;
   Scratch scratch;
@@ -269,14 +285,10 @@ static int grid_reduce(const char* what, const float* points, const int64_t* len
   void* tmp = base + o_tmp;
   int rc = 0;
   do {
-    hipError_t e = hipMemsetAsync(error, 0, sizeof(int), stream);
-    if (e != hipSuccess) {
-      set_last_error("%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
-      rc = (int)e;
-      break;
-    }
+    hipError_t e;
     const unsigned blocks = (unsigned)ceil_div(total, kGsThreads);
-    hipLaunchKernelGGL(gs_minvox_init_kernel, dim3((unsigned)ceil_div((int64_t)B * 3, 256)), dim3(256), 0, stream, minv, B);
+    hipLaunchKernelGGL(gs_init_kernel, dim3((unsigned)ceil_div((int64_t)B * 3, 256)), dim3(256), 0, stream, minv, error,
+                       sampled_lengths, num_sampled, B);
     hipLaunchKernelGGL(gs_minvox_kernel, dim3(B, kGsMinSplit), dim3(kGsThreads), 0, stream, points, lengths, offsets, minv,
                        B, inv);
     hipLaunchKernelGGL(gs_keys_kernel, dim3(blocks), dim3(kGsThreads), 0, stream, points, offsets, minv, k0, v0, error,
