@@ -252,6 +252,74 @@ def test_knn_points_tile_and_prepass_boundaries(ext, oracle_mod, n):
             assert np.array_equal(N_(d), wd), (dtype, k)
 
 
+def _cell_list_clouds(rng):
+    """Clouds of 2048..4096 supports for the per-workgroup cell-list kernel (fp32, k + 1 <= 64, >= 64 queries):
+    name -> (supports (B, N, 3), queries (B, M, 3))."""
+    out = {}
+    s = rng.random((2, 4096, 3), dtype=np.float32)
+    out["uniform_4096"] = (s, np.ascontiguousarray(s[:, ::8]) + np.float32(1e-3))
+    s = rng.random((2, 2048, 3), dtype=np.float32)
+    out["uniform_2048_ragged_queries"] = (s, rng.random((2, 203, 3), dtype=np.float32))
+    # a few tight clusters plus far outliers: almost every support in a handful of cells (runs of more than 64
+    # records), most cells empty, queries between the clusters have to widen ring by ring
+    centres = rng.random((1, 6, 3)).astype(np.float32) * 10
+    c = centres[:, rng.integers(0, 6, 3000)] + rng.normal(0, 0.01, (1, 3000, 3)).astype(np.float32)
+    c[0, :5] = [[100, 100, 100], [-50, 0, 0], [0, 200, 0], [3, 3, 3], [7, 1, 5]]
+    qc = np.concatenate([c[:, ::30], rng.random((1, 60, 3)).astype(np.float32) * 10], axis=1)
+    out["clustered_3000"] = (c.astype(np.float32), qc.astype(np.float32))
+    # integer lattice, shuffled: every query has many equidistant supports -> the heap replay on every row
+    g = np.stack(np.meshgrid(*[np.arange(13)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.5)
+    g = g[rng.permutation(len(g))][None]  # 2197 supports
+    out["lattice_2197"] = (np.ascontiguousarray(g), np.ascontiguousarray(g[:, :96]))
+    # every support repeated 4 times
+    d = np.repeat(unit_sphere_cloud(rng, 1, 640), 4, axis=1)
+    d = d[:, rng.permutation(d.shape[1])]
+    out["dup_2560"] = (np.ascontiguousarray(d), np.ascontiguousarray(d[:, :80]))
+    # flat cloud (one layer of cells along z) with queries off the plane and outside the bounding box
+    f = rng.random((1, 2500, 3), dtype=np.float32)
+    f[..., 2] = 0.25
+    qf = rng.random((1, 100, 3), dtype=np.float32) * 3 - 1
+    out["flat_2500_queries_outside"] = (f, qf.astype(np.float32))
+    # one cloud that is a single point 2100 times, one line
+    one = np.tile(np.float32([[0.3, 0.6, 0.9]]), (1, 2100, 1))
+    line = np.zeros((1, 2100, 3), np.float32)
+    line[0, :, 0] = rng.random(2100, dtype=np.float32)
+    out["degenerate_2100"] = (np.concatenate([one, line]), rng.random((2, 70, 3), dtype=np.float32))
+    # non-finite supports and queries: NaN / +-inf coordinates never enter a list (knn_points_cuda.cuh:80: d < best)
+    n = rng.random((1, 2300, 3), dtype=np.float32)
+    n[0, 5] = np.nan
+    n[0, 77, 1] = np.inf
+    n[0, 1500, 0] = -np.inf
+    n[0, 2000] = 1e6
+    qn = rng.random((1, 64, 3), dtype=np.float32)
+    qn[0, 3, 0] = np.nan
+    qn[0, 9] = np.inf
+    qn[0, 11] = 1e8  # every real distance above the 1e10 sentinel
+    out["nonfinite_2300"] = (n, qn)
+    return out
+
+
+@pytest.mark.parametrize("name", ["uniform_4096", "uniform_2048_ragged_queries", "clustered_3000", "lattice_2197",
+                                  "dup_2560", "flat_2500_queries_outside", "degenerate_2100", "nonfinite_2300"])
+def test_knn_points_cell_list_kernel(ext, oracle_mod, name):
+    """The per-workgroup cell-list kernel (knn_points_grid_kernel: fp32, 2048 <= N <= 4096, M >= 64, k <= 63) is an
+    exact search: indices and distances identical to the oracle's heap on uniform, clustered, tie-heavy, flat,
+    degenerate and non-finite clouds, for k either side of its internal thresholds."""
+    s, q = _cell_list_clouds(np.random.default_rng(77))[name]
+    oracle_mod.set_threads(oracle_mod.max_threads())
+    try:
+        for k in (1, 2, 12, 13, 16, 32, 63):
+            with np.errstate(all="ignore"):
+                wd, wi = oracle_mod.knn_points(q, s, k)
+            d = torch.full((q.shape[0], q.shape[1], k), -1.0, device=DEV)
+            idx = torch.full((q.shape[0], q.shape[1], k), -1, dtype=torch.long, device=DEV)
+            ext.knn_points(T(q), T(s), d, idx, k)
+            assert np.array_equal(N_(idx), wi), (name, k)
+            assert np.array_equal(N_(d), wd, equal_nan=True), (name, k)
+    finally:
+        oracle_mod.set_threads(1)
+
+
 def test_knn_points_k_too_large_raises(ext):
     q = torch.zeros((1, 2, 3), device=DEV)
     with pytest.raises(RuntimeError, match="V3D_ERR_K_TOO_LARGE"):

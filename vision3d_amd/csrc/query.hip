@@ -18,6 +18,8 @@
 // compiled with -ffp-contract=off).
 #include <stdlib.h>
 
+#include <cmath>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -728,14 +730,15 @@ __device__ __forceinline__ double lane_permute(double v, int dst_lane) {
 // (k+1)-th smallest (k = 0..63) of the 64 lanes' non-negative values, or an upper bound of it that is exact in the
 // leading 32 bits: bit-wise binary search on the IEEE pattern (order-preserving for non-negative numbers), one
 // compare + ballot + popcount per bit.  Returns +inf when fewer than k+1 lanes hold a finite value.
-__device__ __forceinline__ float kth_smallest_upper(float v, int k) {
+// `low_bit` > 0 stops the search there and rounds the undecided bits up: a looser bound for fewer ballots.
+__device__ __forceinline__ float kth_smallest_upper(float v, int k, int low_bit = 0) {
   const unsigned bits = __float_as_uint(v);
   unsigned prefix = 0;
-  for (int b = 30; b >= 0; --b) {  // sign bit is 0
+  for (int b = 30; b >= low_bit; --b) {  // sign bit is 0
     const unsigned trial = prefix | (1u << b);
     if (__builtin_popcountll(__ballot(bits < trial)) <= k) prefix = trial;  // the answer is >= trial
   }
-  return __uint_as_float(prefix);
+  return __uint_as_float(prefix | ((1u << low_bit) - 1u));
 }
 __device__ __forceinline__ double kth_smallest_upper(double v, int k) {
   const unsigned hi = (unsigned)(__double_as_longlong(v) >> 32);
@@ -1335,6 +1338,335 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
   }
 }
 
+// ---- knn_points on a per-workgroup cell list (fp32, k + 1 <= 64, 2048 <= N <= 4096) -----------------------------------
+// The brute-force kernels above evaluate every (query, support) pair twice (lane-minimum pre-pass + search): ~53 us of
+// VALU issue at C2 before any candidate is handled.  Here every workgroup (QB queries of one cloud, 512 threads) first
+// sorts the cloud's supports into a G^3 uniform grid over their bounding box, entirely in LDS (count -> scan -> scatter,
+// integer LDS atomics; the three_nn_grid_kernel's builder; ~9 us at N = 4096), then a WAVE serves one query at a time:
+// the 27 cells around it are 9 runs of consecutive records.  A first walk keeps every lane's minimum distance and bounds
+// the (k+1)-th distance from above, a second one batches the candidates under that bound in a 64-slot LDS buffer, and a
+// rank sort (or, once a list exists, the bitonic network of wave_sort.h as in knn_points_merge_kernel) turns them into
+// the sorted list.  The search is exact, not approximate: after the 27 cells (and after every further ring) the
+// (k+1)-th distance is compared with the distance to the nearest face of the explored box that still has cells behind
+// it (minus a rounding margin), and the box grows ring by ring until it is below it or the grid is exhausted.  The
+// result is the k+1 smallest (d2, index) keys of the whole cloud -- the list the other kernels keep -- so ties among
+// them go to the same exact heap replay, and outputs are bit-identical.  G is chosen on the host (knn_points below) so
+// that the ball of the k + 1 nearest fits the 27 cells for most queries of a roughly uniform cloud; a clustered cloud
+// only costs more rings.  Measured at C2 (B 32, N 4096, M 1024): k = 16 113 -> 47 us, k = 32 129 -> 58 us without and
+// 89 us with one tie replay in the launch (profiles/r03_knn_cell_list_sweep.txt).
+constexpr int kKgThreads = 512;
+constexpr int kKgWaves = kKgThreads / 64;
+constexpr int kKgMaxG = 10;
+constexpr int kKgMaxCells = kKgMaxG * kKgMaxG * kKgMaxG;
+constexpr int kKgMaxN = 4096;
+constexpr int kKgMinN = 2048;
+constexpr int kKgPer = kKgMaxN / kKgThreads;  // supports per thread in the builder
+
+__global__ __launch_bounds__(kKgThreads) void knn_points_grid_kernel(const float* __restrict__ q,
+                                                                     const float* __restrict__ s,
+                                                                     float* __restrict__ out_d,
+                                                                     int64_t* __restrict__ out_i, int M, int N, int k,
+                                                                     int G, int QB) {
+  extern __shared__ float4 kg_sorted[];  // N records: x, y, z, index bits -- ordered by cell (x fastest)
+  __shared__ int cell_start[kKgMaxCells + 2];
+  __shared__ int cursor[kKgMaxCells];
+  __shared__ float red[6][kKgWaves];
+  __shared__ int wave_sum[kKgWaves];
+  __shared__ wkey_t hits[kKgWaves][64];
+  __shared__ int next_query;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const float* s_cloud = s + (int64_t)b * N * 3;
+  const int NC = G * G * G;
+  if (tid == 0) next_query = 0;
+
+  // ---- bounding box of the supports ----------------------------------------------------------------------------------
+  float sx[kKgPer], sy[kKgPer], sz[kKgPer];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int u = 0; u < kKgPer; ++u) {
+    const int i = u * kKgThreads + tid;
+    const int ii = i < N ? i : 0;
+    sx[u] = s_cloud[ii * 3 + 0];
+    sy[u] = s_cloud[ii * 3 + 1];
+    sz[u] = s_cloud[ii * 3 + 2];
+    if (i < N) {  // fminf / fmaxf drop NaN: a non-finite support does not poison the box
+      lo[0] = fminf(lo[0], sx[u]); hi[0] = fmaxf(hi[0], sx[u]);
+      lo[1] = fminf(lo[1], sy[u]); hi[1] = fmaxf(hi[1], sy[u]);
+      lo[2] = fminf(lo[2], sz[u]); hi[2] = fmaxf(hi[2], sz[u]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+    }
+    if (lane == 0) {
+      red[a][wave] = lo[a];
+      red[3 + a][wave] = hi[a];
+    }
+  }
+  for (int i = tid; i < NC; i += kKgThreads) cell_start[i] = 0;
+  __syncthreads();
+  float cell[3], inv[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = red[a][0];
+    hi[a] = red[3 + a][0];
+    for (int w = 1; w < kKgWaves; ++w) {
+      lo[a] = fminf(lo[a], red[a][w]);
+      hi[a] = fmaxf(hi[a], red[3 + a][w]);
+    }
+    const float ext = hi[a] - lo[a];
+    cell[a] = (ext > 0.f && ext < INFINITY) ? ext / (float)G : 1.0f;  // flat or unbounded axis: one layer of cells
+    inv[a] = 1.0f / cell[a];
+  }
+  auto coord = [&](float v, int a) {  // NaN and anything outside the box clamp to the border cells
+    const float c = floorf((v - lo[a]) * inv[a]);
+    return c >= (float)(G - 1) ? G - 1 : (c > 0.f ? (int)c : 0);
+  };
+
+  // ---- counting sort of the supports by cell (LDS only) --------------------------------------------------------------
+  int cid[kKgPer];
+#pragma unroll
+  for (int u = 0; u < kKgPer; ++u) {
+    const int i = u * kKgThreads + tid;
+    cid[u] = (coord(sz[u], 2) * G + coord(sy[u], 1)) * G + coord(sx[u], 0);
+    if (i < N) atomicAdd(&cell_start[cid[u]], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan of the NC <= 1000 counts: thread t owns cells 2t, 2t+1
+    const int c0 = 2 * tid < NC ? cell_start[2 * tid] : 0, c1 = 2 * tid + 1 < NC ? cell_start[2 * tid + 1] : 0;
+    const int mine = c0 + c1;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    for (int w = 0; w < wave; ++w) before += wave_sum[w];
+    if (2 * tid < NC) {
+      cell_start[2 * tid] = before;
+      cursor[2 * tid] = before;
+    }
+    if (2 * tid + 1 < NC) {
+      cell_start[2 * tid + 1] = before + c0;
+      cursor[2 * tid + 1] = before + c0;
+    }
+    if (tid == 0) cell_start[NC] = N;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kKgPer; ++u) {
+    const int i = u * kKgThreads + tid;
+    if (i < N) {
+      const int pos = atomicAdd(&cursor[cid[u]], 1);
+      kg_sorted[pos] = make_float4(sx[u], sy[u], sz[u], __int_as_float(i));
+    }
+  }
+  __syncthreads();
+
+  // ---- queries: one per wave at a time -------------------------------------------------------------------------------
+  const float sentinel = 1e10f;  // knn_points_cuda.cuh:71: nothing >= 1e10 ever enters
+  const wkey_t sent_key = (wkey_t)__float_as_uint(sentinel) << 32;
+  wkey_t* buf = hits[wave];
+  // Queries are handed out through an LDS counter, one ahead: the coordinates of a wave's next query arrive while it
+  // serves the current one, and a wave held up by a tie replay leaves the rest of the block to the others.
+  const int q_begin = blockIdx.x * QB, q_count = min(M, q_begin + QB) - q_begin;
+  auto grab = [&]() {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(&next_query, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  auto fetch = [&](int t, float& x, float& y, float& z) {
+    const float* qp = q + ((int64_t)b * M + q_begin + min(t, q_count - 1)) * 3;
+    x = qp[0];
+    y = qp[1];
+    z = qp[2];
+  };
+  int cur = grab();
+  float nx, ny, nz;
+  fetch(cur, nx, ny, nz);
+  while (cur < q_count) {
+    const int qi = q_begin + cur;
+    // wave-uniform values in scalar registers: the cell walk below then runs on scalar loop bounds
+    const float qx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nx)));
+    const float qy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ny)));
+    const float qz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nz)));
+    cur = grab();
+    fetch(cur, nx, ny, nz);
+    const float qv[3] = {qx, qy, qz};
+    const int cc[3] = {__builtin_amdgcn_readfirstlane(coord(qx, 0)), __builtin_amdgcn_readfirstlane(coord(qy, 1)),
+                       __builtin_amdgcn_readfirstlane(coord(qz, 2))};
+    wkey_t kept = sent_key, worst = sent_key;
+    int pending = 0;
+    bool kept_empty = true;
+    // 64 candidate keys, one per lane, `take` marks the live ones: batched in the wave's LDS buffer, merged when it fills
+    auto offer_key = [&](wkey_t key, bool take) {
+      const unsigned long long m = __ballot(take);
+      if (m == 0ull) return;
+      const int n = __builtin_popcountll(m);
+      const int dest = pending + wave_prefix_count(m);
+      if (take && dest < 64) buf[dest] = key;
+      if (pending + n >= 64) {
+        kept = wave_merge_buffer(kept, buf, 64, lane);
+        kept_empty = false;
+        worst = wave_lane64(kept, k);
+        if (take && dest >= 64) buf[dest - 64] = key;
+        pending += n - 64;
+      } else {
+        pending += n;
+      }
+    };
+    auto offer = [&](int j, bool valid, float cap) {  // records j (lane-varying) of the sorted list
+      const float4 p = kg_sorted[valid ? j : 0];
+      const float d = sq_dist(qx, qy, qz, p.x, p.y, p.z);
+      const wkey_t key = ((wkey_t)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+      offer_key(key, valid && key < worst && d <= cap);  // NaN / +inf patterns lie above the sentinel's
+    };
+    auto scan_run = [&](int j0_, int j1_) {  // wave-uniform bounds (read from LDS: moved to scalar registers)
+      const int j0 = __builtin_amdgcn_readfirstlane(j0_), j1 = __builtin_amdgcn_readfirstlane(j1_);
+      for (int j = j0; j < j1; j += 64) offer(j + lane, j + lane < j1, INFINITY);
+    };
+    // The 27 cells are 9 runs of consecutive records; their bounds are fetched by lanes 0..8 in one LDS round trip and
+    // moved to scalar registers.  Run r is dealt to the lanes from lane (records before it) mod 64 on, as if the runs
+    // were concatenated, so every lane sees its share of the candidates.  First walk: the distances (one step of 64 per
+    // run stays in registers) and every lane's minimum.  The (k+1)-th smallest of the 64 minima is attained by k+1
+    // distinct supports, i.e. bounds the (k+1)-th distance from above (knn_lane_min_bound's argument; the search stops
+    // at bit 17 of the pattern and rounds up: <= 1.6 % looser, 14 ballots instead of 31), and admits little more than
+    // k+1 candidates to the second walk: one merge per query.
+    {
+      int rb = 0, rn = 0;
+      if (lane < 9) {
+        const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, G - 1);
+        const int zz = cc[2] - 1 + lane / 3, yy = cc[1] - 1 + lane % 3;
+        if (zz >= 0 && zz < G && yy >= 0 && yy < G) {
+          const int c0 = (zz * G + yy) * G;
+          rb = cell_start[c0 + x0];
+          rn = cell_start[c0 + x1 + 1] - rb;
+        }
+      }
+      int beg[9], len[9], pre = 0;
+      float dr[9];
+      unsigned wr[9];
+      float lmin = INFINITY;
+      bool long_run = false;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        beg[r] = __builtin_amdgcn_readlane(rb, r);
+        len[r] = __builtin_amdgcn_readlane(rn, r);
+        const int jr = (lane - pre) & 63;
+        const bool valid = jr < len[r];
+        const float4 p = kg_sorted[valid ? beg[r] + jr : 0];
+        const float d = sq_dist(qx, qy, qz, p.x, p.y, p.z);
+        dr[r] = valid ? d : __uint_as_float(0x7fc00000u);  // an idle lane's entry never passes a comparison
+        wr[r] = (unsigned)__float_as_int(p.w);
+        lmin = (valid && d < lmin) ? d : lmin;  // +inf and NaN never replace a minimum
+        for (int j = 64; j < len[r]; j += 64) {  // (a crowded run: more than 64 records)
+          const int jj = j + jr;
+          const float4 p2 = kg_sorted[jj < len[r] ? beg[r] + jj : 0];
+          const float d2 = sq_dist(qx, qy, qz, p2.x, p2.y, p2.z);
+          lmin = (jj < len[r] && d2 < lmin) ? d2 : lmin;
+          long_run = true;
+        }
+        pre += len[r];
+      }
+      const float capk = pre > 64 ? kth_smallest_upper(lmin, k, 17) : INFINITY;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const wkey_t key = ((wkey_t)__float_as_uint(dr[r]) << 32) | wr[r];
+        offer_key(key, key < worst && dr[r] <= capk);
+      }
+      if (long_run) {
+        int pre2 = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+          const int jr = (lane - pre2) & 63;
+          for (int j = 64; j < len[r]; j += 64) offer(beg[r] + j + jr, j + jr < len[r], capk);
+          pre2 += len[r];
+        }
+      }
+    }
+    int p0[3], p1[3];  // explored box
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      p0[a] = max(cc[a] - 1, 0);
+      p1[a] = min(cc[a] + 1, G - 1);
+    }
+    for (int R = 2;; ++R) {
+      if (pending > 0) {  // the bound below needs the true (k+1)-th key
+        if (kept_empty) {
+          const wkey_t h = wave_rank_sort(buf, pending, lane);
+          kept = h < sent_key ? h : sent_key;
+        } else {
+          kept = wave_merge_buffer(kept, buf, pending, lane);
+        }
+        kept_empty = false;
+        worst = wave_lane64(kept, k);
+        pending = 0;
+      }
+      // nearest face of the explored box that still has cells behind it
+      float bound = INFINITY;
+      bool open = false;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float rel = qv[a] - lo[a];
+        const float margin = 1e-5f * fmaxf(hi[a] - lo[a], fabsf(rel));
+        if (p0[a] > 0) {
+          open = true;
+          bound = fminf(bound, fmaxf(rel - (float)p0[a] * cell[a] - margin, 0.f));
+        }
+        if (p1[a] < G - 1) {
+          open = true;
+          bound = fminf(bound, fmaxf((float)(p1[a] + 1) * cell[a] - rel - margin, 0.f));
+        }
+      }
+      const float dk = __uint_as_float((unsigned)(worst >> 32));
+      if (!open || dk < bound * bound) break;  // (NaN bounds compare false: the search widens to the whole grid)
+      int r0[3], r1[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        r0[a] = max(cc[a] - R, 0);
+        r1[a] = min(cc[a] + R, G - 1);
+      }
+      for (int z = r0[2]; z <= r1[2]; ++z) {
+        for (int y = r0[1]; y <= r1[1]; ++y) {
+          const int row = (z * G + y) * G;
+          const bool inner = z >= p0[2] && z <= p1[2] && y >= p0[1] && y <= p1[1];
+          if (!inner) {
+            scan_run(cell_start[row + r0[0]], cell_start[row + r1[0] + 1]);
+          } else {
+            if (r0[0] < p0[0]) scan_run(cell_start[row + r0[0]], cell_start[row + p0[0]]);
+            if (r1[0] > p1[0]) scan_run(cell_start[row + p1[0] + 1], cell_start[row + r1[0] + 1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        p0[a] = r0[a];
+        p1[a] = r1[a];
+      }
+    }
+    float* od = out_d + ((int64_t)b * M + qi) * k;
+    int64_t* oi = out_i + ((int64_t)b * M + qi) * k;
+    const float d = __uint_as_float((unsigned)(kept >> 32));
+    const float below = shr1_fill(d, -1.0f);
+    // equal real distances among ranks 0..k -> the heap's mechanics matter
+    const unsigned long long ties = __ballot(lane >= 1 && lane <= k && d == below && d < sentinel);
+    if (ties != 0ull) {
+      knn_exact_replay_lanes<float, 1>(s_cloud, N, k, qx, qy, qz, od, oi);
+    } else if (lane < k) {
+      od[lane] = sqrtf(d);  // :90
+      oi[lane] = (int64_t)(unsigned)kept;
+    }
+  }
+}
+
 template <typename T>
 static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, int N, int k, int device,
                       void* stream_) {
@@ -1357,6 +1689,33 @@ static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, 
   constexpr int TS = 1024;
   dim3 grid((unsigned)ceil_div(M, kWavesPerBlock * QPW), (unsigned)B), block(kQueryThreads);
   if constexpr (std::is_same<T, float>::value) {
+    // per-workgroup cell list: clouds whose supports fit LDS and that are large enough to pay for sorting them (at
+    // N = 1024 the ~9 us builder eats the gain: 22.7 us at best against 24.5 us brute force, profiles/r03_knn_cell_list_sweep.txt)
+    if (k + 1 <= 64 && N >= kKgMinN && N <= kKgMaxN && M >= 64) {
+      // >= 12 supports per cell: a run of three cells then fills most of a 64-lane step; from k ~ 33 up 0.36 (k + 1),
+      // so that the ball of the k + 1 nearest of a uniform cloud stays inside the 27 cells (cell edge >= 1.15 radii)
+      const double per_cell = std::max(12.0, 0.36 * (k + 1));
+      int G = (int)std::lround(std::cbrt((double)N / per_cell));
+      G = std::max(3, std::min(G, kKgMaxG));
+      // queries per workgroup: every workgroup sorts the whole cloud, so as many as still leave ~2 workgroups per CU
+      int QB = 64;
+      while (QB > 16 && (int64_t)B * ceil_div(M, QB) < 512) QB >>= 1;
+      static std::mutex attr_mutex;
+      static bool attr_set[64] = {};
+      {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (device < 0 || device >= 64 || !attr_set[device]) {
+          V3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_points_grid_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kKgMaxN * (int)sizeof(float4)),
+                      what);
+          if (device >= 0 && device < 64) attr_set[device] = true;
+        }
+      }
+      dim3 ggrid((unsigned)ceil_div(M, QB), (unsigned)B);
+      hipLaunchKernelGGL(knn_points_grid_kernel, ggrid, dim3(kKgThreads), (size_t)N * sizeof(float4), stream, q, s, od, oi,
+                         M, N, k, G, QB);
+      return launch_status(what);
+    }
     // batched survivors + bitonic merge: 14-25 % faster than the list from k ~ 24 up, slower below k ~ 12
     if (k >= 24 && k + 1 <= 64) {
       hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0);

@@ -66,6 +66,22 @@ __device__ __forceinline__ wkey_t wave_merge_buffer(wkey_t kept, const wkey_t* b
   }
   return kept;
 }
+// The first n (wave-uniform, 0..64) DISTINCT keys of a per-wave LDS buffer -> ascending across the lanes, kWaveKeyMax behind
+// them.  Every lane counts the keys below its own (n broadcast reads, no cross-lane round trips) and the keys change
+// places through the buffer: cheaper than the 21-step network while n is a few dozen.  The buffer is left sorted.
+__device__ __forceinline__ wkey_t wave_rank_sort(wkey_t* buf, int n, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  const wkey_t mine = lane < n ? buf[lane] : kWaveKeyMax;
+  int rank = 0;
+#pragma unroll 8
+  for (int e = 0; e < n; ++e) rank += buf[e] < mine ? 1 : 0;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < n) buf[rank] = mine;
+  __builtin_amdgcn_wave_barrier();
+  const wkey_t out = lane < n ? buf[lane] : kWaveKeyMax;
+  __builtin_amdgcn_wave_barrier();
+  return out;
+}
 __device__ __forceinline__ int wave_prefix_count(unsigned long long m) {  // set bits of m below this lane
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
