@@ -219,14 +219,23 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
                                size_t workspace_bytes, int device, void* stream);
 /* Pack-mode kNN, replaces vision3d/ops/knn.py:110-145 (pack -> batch padded with points at 1e10 -> pykeops kNN -> pack):
  * for every query the k nearest supports of ITS OWN cloud: distances (total_q,k) = sqrt of the squared distance,
- * ascending; indices (total_q,k) i64 = positions inside the cloud (what the reference's padded batch yields), order among
- * equal distances as v3d_knn_points_f32.  k <= V3D_KNN_MAX_K; a cloud with fewer than k supports (the reference asserts
- * against it, :137) leaves (1e5, 0) in the unfilled slots like v3d_knn_points_f32.  No host synchronisation.  Scratch:
- * v3d_knn_pack_workspace_bytes(B) bytes or NULL (stream-ordered allocation). */
-size_t v3d_knn_pack_workspace_bytes(int B);
+ * ascending; indices (total_q,k) i64 = positions inside the cloud (what the reference's padded batch yields).  Equal
+ * distances come lower index first -- ascending (d2, index), the order of pykeops' Kmin_argKmin (strict-< insertion while
+ * scanning the supports in index order) and of v3d_radius_search_pack_f32; NOT the heap order of v3d_knn_points_f32.
+ * k <= V3D_KNN_MAX_K; a cloud with fewer than k supports (the reference asserts against it, :137) leaves (1e5, 0) in the
+ * unfilled slots like v3d_knn_points_f32; lengths that overrun the totals are cut.  Clouds averaging >= 2048 supports
+ * (k <= 64, B <= 4096) are searched on the radius search's cell list, smaller ones pair by pair.  No host
+ * synchronisation.  Scratch: v3d_knn_pack_workspace_bytes(B, total_s, k) bytes or NULL (stream-ordered allocation). */
+size_t v3d_knn_pack_workspace_bytes(int B, int64_t total_s, int k);
 int v3d_knn_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
                      float* distances, int64_t* indices, int B, int64_t total_q, int64_t total_s, int k,
                      void* workspace, size_t workspace_bytes, int device, void* stream);
+/* Batch-mode kNN of 3-D points in pykeops' order: what vision3d/ops/knn.py:10-27 (Kmin_argKmin of the Euclidean norm)
+ * yields for q (B,M,3) and s (B,N,3): distances (B,M,k) ascending, equal distances lower index first -- the kernels of
+ * v3d_knn_points_f32 without the heap replay, with its limits (k <= V3D_KNN_MAX_K) and its (1e5, 0) in the slots a cloud
+ * of fewer than k supports leaves unfilled.  ops.knn sends 3-D inputs here, any other channel count to v3d_knn_feat_f32. */
+int v3d_knn_lex_f32(const float* q, const float* s, float* distances, int64_t* indices, int B, int M, int N, int k,
+                    int device, void* stream);
 /* Radius count, replaces vision3d/ops/radius_search.py:74-107 (pack -> padded batch -> pykeops sum of
  * relu(radius - d).sign() -> pack): counts (total_q,) = the number of supports of the query's own cloud with
  * radius - sqrt(d2) > 0 (strict).  Same cell list, workspace and limits as the search above. */

@@ -204,6 +204,19 @@ def knn_feat(x, y, k):
     return dist.reshape(lead + (N, k)), idx.reshape(lead + (N, k))
 
 
+def knn_pack(q_points, s_points, q_lengths, s_lengths, k):
+    """Pack-mode kNN (ops/knn.py:110-145): (dist (total_q, k) f32, idx (total_q, k) i64 inside the cloud), equal
+    distances lower index first (pykeops' insertion order; parity unpinned)."""
+    q = _c(q_points, np.float32)
+    s = _c(s_points, np.float32)
+    ql = _c(q_lengths, np.int64)
+    sl = _c(s_lengths, np.int64)
+    dist = np.zeros((q.shape[0], int(k)), dtype=np.float32)
+    idx = np.zeros((q.shape[0], int(k)), dtype=np.int64)
+    lib().v3d_oracle_knn_pack_f32(_p(q), _p(s), _p(ql), _p(sl), _p(dist), _p(idx), int(ql.shape[0]), int(k))
+    return dist, idx
+
+
 def radius_search_pack(q_points, s_points, q_lengths, s_lengths, radius, neighbor_limit):
     """Pack-mode radius search (ops/radius_search.py:44-71): (total_q, limit) i64, absent = total_s."""
     q = _c(q_points, np.float32)

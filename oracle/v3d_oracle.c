@@ -431,6 +431,50 @@ void v3d_oracle_radius_search_pack_f32(const float* q, const float* s, const int
   }
 }
 
+/* kNN in pack mode, restated from ops/knn.py:110-145: every cloud padded to the longest with points at 1e10 (:138-139),
+ * keops_knn over the padded batch (:140; pykeops, third-party and absent -> "parity unpinned": Kmin_argKmin inserts with a
+ * strict '<' while it scans the supports in index order, i.e. ascending distance, equal distances by lower index), the
+ * rows of the real queries taken back (:141-145).  Indices are positions inside the cloud.  Arithmetic as everywhere in
+ * this file: fp32 (dx*dx + dy*dy) + dz*dz, sqrtf of it on output.  A cloud with fewer than k supports (the reference
+ * asserts against it, :137) leaves (1e5, 0) in the unfilled slots and nothing at or beyond 1e10 enters -- the convention
+ * of v3d_oracle_knn_points (knn_points_cuda.cuh:70-73,80), kept so that the two entry points differ in the order of
+ * equal distances only. */
+void v3d_oracle_knn_pack_f32(const float* q, const float* s, const int64_t* q_len, const int64_t* s_len, float* kd,
+                             int64_t* ki, int B, int k) {
+  int64_t q_off = 0, s_off = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t nq = q_len[b], ns = s_len[b];
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+    for (int64_t a = 0; a < nq; ++a) {
+      const float* qp = q + (size_t)(q_off + a) * 3;
+      float* bd = kd + (size_t)(q_off + a) * k;
+      int64_t* bi = ki + (size_t)(q_off + a) * k;
+      for (int n = 0; n < k; ++n) {
+        bd[n] = 1e10f;
+        bi[n] = 0;
+      }
+      for (int64_t j = 0; j < ns; ++j) {
+        const float* sp = s + (size_t)(s_off + j) * 3;
+        float dx = qp[0] - sp[0], dy = qp[1] - sp[1], dz = qp[2] - sp[2];
+        float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (k > 0 && d2 < bd[k - 1]) { /* strict: an equal distance met later stays behind */
+          int pos = k - 1;
+          while (pos > 0 && bd[pos - 1] > d2) {
+            bd[pos] = bd[pos - 1];
+            bi[pos] = bi[pos - 1];
+            --pos;
+          }
+          bd[pos] = d2;
+          bi[pos] = j;
+        }
+      }
+      for (int n = 0; n < k; ++n) bd[n] = sqrtf(bd[n]);
+    }
+    q_off += nq;
+    s_off += ns;
+  }
+}
+
 /* Grid subsampling in pack mode, restated from ops/grid_subsample.py:49-99: voxel = floor(point * float(1/voxel_size))
  * (:64-65, float32 product), minus the cloud's minimum voxel (:75); one output point per occupied voxel, ordered like
  * torch.unique of the raveled (cloud, vx, vy, vz) hash (:82-85), i.e. by cloud then lexicographically; its value is the

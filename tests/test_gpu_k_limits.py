@@ -1,7 +1,8 @@
 """Searches beyond the lane-list sizes, and pack-mode kNN without padding:
   * v3d_knn_feat_f32 with k > 64 (workgroup-per-row selection; pykeops' Kmin_argKmin, ops/knn.py:26, has no limit);
   * v3d_radius_search_pack_f32 with neighbor_limit > 128 (ops/radius_search.py:44-71 passes any limit to pykeops);
-  * v3d_knn_pack_f32 behind ops.knn_pack_mode (ops/knn.py:110-145) against the knn_points oracle, cloud by cloud.
+  * v3d_knn_pack_f32 behind ops.knn_pack_mode (ops/knn.py:110-145) against the pack-mode kNN oracle (equal distances
+    lower index first), on the pair-by-pair kernels (small clouds) and on the cell list (clouds of >= 2048 supports).
 Bars as in test_gpu_parity.py: indices bit-exact for the 3-D searches; the feature search to fp32 distance resolution."""
 import importlib
 import os
@@ -10,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import lattice_cloud
+from conftest import lattice_cloud, unit_sphere_cloud
 
 pytestmark = pytest.mark.gpu
 
@@ -203,23 +204,14 @@ def test_radius_neighbors_numpy_entry_widens_its_table(ext, oracle_mod):
 # pack-mode kNN on the packed arrays
 # ------------------------------------------------------------------------------------------------------
 def _knn_pack_oracle(oracle_mod, q, s, ql, sl, k):
-    d = np.zeros((q.shape[0], k), np.float32)
-    i = np.zeros((q.shape[0], k), np.int64)
-    qo = so = 0
-    for a, b in zip(ql, sl):
-        if a:
-            wd, wi = oracle_mod.knn_points(q[None, qo:qo + a], s[None, so:so + b], k)
-            d[qo:qo + a], i[qo:qo + a] = wd[0], wi[0]
-        qo += a
-        so += b
-    return d, i
+    return oracle_mod.knn_pack(q, s, ql, sl, k)
 
 
 @pytest.mark.parametrize("case", [
     dict(q=(150, 90, 200), s=(150, 90, 200)),
     dict(q=(17, 0, 1, 400, 16), s=(300, 50, 120, 2500, 101)),   # empty query cloud, single query, partly filled workgroups
     dict(q=(1000,), s=(1200,)),
-    dict(q=(216, 100), s=(216, 512), lattice=True),               # equal distances: the heap replay decides
+    dict(q=(216, 100), s=(216, 512), lattice=True),               # equal distances: the lower index first
 ])
 @pytest.mark.parametrize("k", [1, 5, 16, 30, 63, 64, 100])
 def test_knn_pack_native_vs_per_cloud_oracle(ext, oracle_mod, case, k):
@@ -238,6 +230,157 @@ def test_knn_pack_native_vs_per_cloud_oracle(ext, oracle_mod, case, k):
     ext.knn_pack(T(q), T(s), T(ql), T(sl), d, idx, k)
     assert np.array_equal(N_(idx), wi)
     assert np.array_equal(N_(d), wd)
+
+
+def _cell_list_pack_case(name, rng):
+    """(query clouds, support clouds) whose supports average >= 2048 per cloud: the cell-list route of v3d_knn_pack_f32."""
+    if name == "uniform":
+        sc = [rng.random((n, 3), dtype=np.float32) * np.float32([3, 3, 2.5]) for n in (3000, 2500, 5000)]
+        qc = [rng.random((n, 3), dtype=np.float32) * np.float32([3, 3, 2.5]) for n in (700, 0, 900)]
+    elif name == "queries_are_supports":  # every query has itself at distance 0
+        sc = [rng.random((n, 3), dtype=np.float32) for n in (4000, 2200)]
+        qc = [c[::5].copy() for c in sc]
+    elif name == "surface":  # points on a sphere and on two planes: most cells of the box are empty
+        v = rng.standard_normal((5000, 3)).astype(np.float32)
+        sphere = v / np.linalg.norm(v, axis=1, keepdims=True)
+        planes = rng.random((4000, 3), dtype=np.float32) * 4
+        planes[:2000, 2] = 0.0
+        planes[2000:, 0] = 4.0
+        sc = [sphere.astype(np.float32), planes]
+        qc = [np.concatenate([sphere[::20] * np.float32(0.3), sphere[::25]]).astype(np.float32),
+              (rng.random((300, 3), dtype=np.float32) * 4)]
+    elif name == "clusters_and_far_queries":  # distant clusters: rings run out, the linear scan of the cloud finishes
+        cen = rng.random((5, 3)).astype(np.float32) * 100
+        c = (cen[rng.integers(0, 5, 6000)] + rng.normal(0, 0.05, (6000, 3))).astype(np.float32)
+        far = (rng.random((150, 3)) * 300 - 100).astype(np.float32)
+        sc = [c]
+        qc = [np.concatenate([c[::40], far]).astype(np.float32)]
+    elif name == "lattice_ties":  # integer lattice, shuffled: equal distances everywhere -> lower index first
+        g = np.stack(np.meshgrid(*[np.arange(14)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.5)
+        a = g[rng.permutation(len(g))]   # 2744
+        b = g[rng.permutation(len(g))]
+        sc = [a, b]
+        qc = [a[:150].copy(), (b[:100] + np.float32(0.25)).astype(np.float32)]
+    elif name == "duplicates_and_flat":
+        d = np.repeat(rng.random((600, 3), dtype=np.float32), 5, axis=0)
+        d = d[rng.permutation(len(d))]  # 3000, every point five times
+        f = rng.random((2500, 3), dtype=np.float32)
+        f[:, 1] = 0.5
+        one = np.tile(np.float32([[1.0, 2.0, 3.0]]), (2100, 1))
+        sc = [d, f, one]
+        qc = [d[:120].copy(), rng.random((130, 3), dtype=np.float32), rng.random((40, 3), dtype=np.float32) * 3]
+    elif name == "nonfinite":
+        a = rng.random((2600, 3), dtype=np.float32)
+        a[7] = np.nan
+        a[100, 2] = np.inf       # the cloud's box is not finite: one cell, every support a candidate
+        b = rng.random((2400, 3), dtype=np.float32)
+        b[3, 0] = np.nan         # NaN only: dropped from the box, parked in a border cell
+        b[50] = 2e5              # farther than the 1e10 sentinel from everything
+        qa = rng.random((90, 3), dtype=np.float32)
+        qa[4] = np.nan
+        qb = rng.random((70, 3), dtype=np.float32)
+        qb[5, 1] = np.inf
+        qb[6] = 1e8
+        sc, qc = [a, b], [qa, qb]
+    else:
+        raise KeyError(name)
+    return qc, sc
+
+
+@pytest.mark.parametrize("name", ["uniform", "queries_are_supports", "surface", "clusters_and_far_queries",
+                                  "lattice_ties", "duplicates_and_flat", "nonfinite"])
+def test_knn_pack_cell_list_vs_oracle(ext, oracle_mod, name):
+    """Clouds of a few thousand supports: v3d_knn_pack_f32 searches them on the radius search's cell list.  The search
+    is exact -- identical indices and distances to the pair-by-pair oracle, equal distances lower index first -- on
+    uniform, surface-like, clustered, tie-heavy, degenerate and non-finite clouds."""
+    qc, sc = _cell_list_pack_case(name, np.random.default_rng(91))
+    q, s = np.concatenate(qc), np.concatenate(sc)
+    ql = np.asarray([len(c) for c in qc], np.int64)
+    sl = np.asarray([len(c) for c in sc], np.int64)
+    assert s.shape[0] // len(sl) >= 2048
+    oracle_mod.set_threads(oracle_mod.max_threads())
+    try:
+        for k in (1, 3, 16, 38, 64):
+            with np.errstate(all="ignore"):
+                wd, wi = oracle_mod.knn_pack(q, s, ql, sl, k)
+            d = torch.full((q.shape[0], k), -1.0, device=DEV)
+            idx = torch.full((q.shape[0], k), -7, dtype=torch.long, device=DEV)
+            ext.knn_pack(T(q), T(s), T(ql), T(sl), d, idx, k)
+            assert np.array_equal(N_(idx), wi), (name, k)
+            assert np.array_equal(N_(d), wd, equal_nan=True), (name, k)
+    finally:
+        oracle_mod.set_threads(1)
+
+
+def test_knn_pack_cell_list_equals_pairwise_kernels_at_pyramid_size(ext):
+    """16 clouds x 30,000 supports (config C4's finest level), 7,500 queries each: the cell list and the pair-by-pair
+    kernels (reached by cutting the same supports into one cloud per call below the cell list's size) agree."""
+    g = torch.Generator().manual_seed(5)
+    nc, ns, nq, k = 4, 30000, 2000, 16
+    box = torch.tensor([3.0, 3.0, 2.5])
+    s = (torch.rand((nc * ns, 3), generator=g) * box).to(DEV)
+    q = (torch.rand((nc * nq, 3), generator=g) * box).to(DEV)
+    ql = torch.full((nc,), nq, dtype=torch.long, device=DEV)
+    sl = torch.full((nc,), ns, dtype=torch.long, device=DEV)
+    d = torch.empty((nc * nq, k), device=DEV)
+    i = torch.empty((nc * nq, k), dtype=torch.long, device=DEV)
+    ext.knn_pack(q, s, ql, sl, d, i, k)
+    # brute force per cloud with torch (fp32 differences, same expression order)
+    for c in range(nc):
+        qq, ss = q[c * nq:(c + 1) * nq], s[c * ns:(c + 1) * ns]
+        dx = qq[:, None, 0] - ss[None, :, 0]
+        dy = qq[:, None, 1] - ss[None, :, 1]
+        dz = qq[:, None, 2] - ss[None, :, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz
+        wd, wi = torch.topk(d2, k, dim=1, largest=False, sorted=True)
+        assert torch.equal(d[c * nq:(c + 1) * nq], wd.sqrt())
+        same = i[c * nq:(c + 1) * nq] == wi
+        # (torch.topk leaves the order of equal distances open: rows may differ there only)
+        rows = ~same.all(dim=1)
+        if rows.any():
+            dd = wd[rows]
+            assert bool(((dd[:, 1:] == dd[:, :-1]).any(dim=1)).all())
+
+
+@pytest.mark.parametrize("name", ["lattice", "lattice_large", "dup", "uniform_cell_list", "few_supports"])
+def test_knn_lex_index_order_vs_oracle(ext, oracle_mod, name):
+    """v3d_knn_lex_f32 (what ops.knn runs for 3-D points): the knn_points kernels -- list, merge and per-workgroup cell
+    list -- leaving equal distances lower index first instead of replaying the heap."""
+    from vision3d_amd import ops
+
+    rng = np.random.default_rng(17)
+    if name == "lattice":
+        s = np.concatenate([lattice_cloud(8, 0.125, shuffle_seed=3), lattice_cloud(8, 0.125, shuffle_seed=4)])
+        q = np.ascontiguousarray(s[:, :70])
+    elif name == "lattice_large":  # 2744 supports, 96 queries: the cell-list kernel
+        g = np.stack(np.meshgrid(*[np.arange(14)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.5)
+        s = np.stack([g[rng.permutation(len(g))] for _ in range(2)])
+        q = np.ascontiguousarray(s[:, :96])
+    elif name == "dup":
+        s = np.repeat(unit_sphere_cloud(rng, 2, 300), 3, axis=1)
+        q = np.ascontiguousarray(s[:, ::9])
+    elif name == "uniform_cell_list":
+        s = rng.random((2, 4096, 3), dtype=np.float32)
+        q = np.ascontiguousarray(s[:, ::16]) + np.float32(1e-3)
+    else:  # fewer supports than neighbours: (1e5, 0) in the unfilled slots
+        s = rng.random((2, 5, 3), dtype=np.float32)
+        q = rng.random((2, 9, 3), dtype=np.float32)
+    B, M, N = q.shape[0], q.shape[1], s.shape[1]
+    ql, sl = np.full((B,), M, np.int64), np.full((B,), N, np.int64)
+    oracle_mod.set_threads(oracle_mod.max_threads())
+    try:
+        for k in (1, 7, 16, 32, 63, 64, 100):
+            wd, wi = oracle_mod.knn_pack(q.reshape(-1, 3), s.reshape(-1, 3), ql, sl, k)
+            d = torch.full((B, M, k), -1.0, device=DEV)
+            idx = torch.full((B, M, k), -7, dtype=torch.long, device=DEV)
+            ext.knn_lex(T(q), T(s), d, idx, k)
+            assert np.array_equal(N_(idx).reshape(-1, k), wi), (name, k)
+            assert np.array_equal(N_(d).reshape(-1, k), wd), (name, k)
+            if k <= N:
+                od, oi = ops.knn(T(q), T(s), k, return_distance=True)
+                assert torch.equal(oi, idx) and torch.equal(od, d)
+    finally:
+        oracle_mod.set_threads(1)
 
 
 def test_knn_pack_mode_op_matches_padded_route_and_keeps_the_assertion(ext, oracle_mod):

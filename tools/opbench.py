@@ -131,6 +131,17 @@ def main():
             add(f"radius_count padded brute-force route clouds{nc} n{n} r{r}",
                 lambda pts=pts, lengths=lengths, r=r: padded_radius_count_pack_mode(pts, pts, lengths, lengths, r),
                 nc * n, "Mq/s")
+    # pack-mode kNN (ops/knn.py:110-145): decoder upsampling (fine <- coarse, k = 1 / 3) and same-level neighbourhoods
+    for (nc, nq, ns, k) in ((16, 30000, 7500, 1), (16, 30000, 7500, 3), (16, 7500, 7500, 16), (16, 30000, 30000, 16)):
+        box = torch.tensor([3.0, 3.0, 2.5])
+        qp = (torch.rand((nc * nq, 3), generator=g) * box).to(DEV)
+        sp = (torch.rand((nc * ns, 3), generator=g) * box).to(DEV)
+        ql = torch.full((nc,), nq, dtype=torch.long, device=DEV)
+        sl = torch.full((nc,), ns, dtype=torch.long, device=DEV)
+        kd = torch.empty((nc * nq, k), device=DEV)
+        ki = torch.empty((nc * nq, k), dtype=torch.long, device=DEV)
+        add(f"knn_pack clouds{nc} q{nq} s{ns} k{k}",
+            lambda qp=qp, sp=sp, ql=ql, sl=sl, kd=kd, ki=ki, k=k: ext.knn_pack(qp, sp, ql, sl, kd, ki, k), nc * nq, "Mq/s")
     for (nc, n, vs) in ((16, 30000, 0.025), (16, 30000, 0.1)):
         pts = (torch.rand((nc * n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
         lengths = torch.full((nc,), n, dtype=torch.long, device=DEV)

@@ -35,6 +35,7 @@ SIGNATURES = {
                  _c_int, _c_int] + _TAIL),
     "v3d_knn_points_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_knn_points_f64": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _TAIL),
+    "v3d_knn_lex_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_three_nn_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_three_nn_f64": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int] + _TAIL),
     "v3d_radius_count_f32": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32] + _TAIL),
@@ -74,7 +75,7 @@ SIGNATURES = {
     "v3d_radius_search_workspace_bytes": (_c_size, [_c_int, _c_i64]),
     "v3d_radius_search_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32, _c_int] + _WS + _TAIL),
-    "v3d_knn_pack_workspace_bytes": (_c_size, [_c_int]),
+    "v3d_knn_pack_workspace_bytes": (_c_size, [_c_int, _c_i64, _c_int]),
     "v3d_knn_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_int] + _WS + _TAIL),
     "v3d_radius_count_pack_f32": (

@@ -101,6 +101,15 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // Grid dims y/z are limited to 65535; x to 2^31-1.
 constexpr int kMaxGridYZ = 65535;
 
+// radius.hip: pack-mode kNN (k <= 64, at most 4096 clouds) on the radius search's cell list -- query.hip's knn_pack
+// sends the clouds that are worth a grid there.
+constexpr int kKnnCellListMaxK = 64;
+constexpr int kKnnCellListMaxClouds = 4096;
+int knn_pack_cell_list(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
+                       float* distances, int64_t* indices, int B, int64_t total_q, int64_t total_s, int k,
+                       void* workspace, size_t workspace_bytes, int device, void* stream);
+size_t knn_pack_cell_list_workspace_bytes(int B, int64_t total_s);
+
 
 // XCD-aware workgroup placement.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with a private
 // 4 MiB L2.  All position tiles and channel tiles of one cloud re-read that cloud's source rows and indices, so the

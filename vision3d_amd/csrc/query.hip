@@ -1104,7 +1104,7 @@ template <typename T, int R, int QPW, int TS, bool PACK = false>
 __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __restrict__ q, const T* __restrict__ s,
                                                                    T* __restrict__ out_d, int64_t* __restrict__ out_i,
                                                                    int M_arg, int N_arg, int k,
-                                                                   const KnnPackPlan* __restrict__ plan, int B) {
+                                                                   const KnnPackPlan* __restrict__ plan, int B, int lex) {
   __shared__ __align__(16) T tile[TS * 3];
   const KnnWhere where = knn_where<PACK>(M_arg, N_arg, plan, B);
   if (!where.live) return;  // the whole workgroup
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_kernel(const T* __re
       ties |= __ballot(rank >= 1 && rank <= k && list[g].d[r] == below && list[g].d[r] < sentinel);
       prev_last = read_lane(list[g].d[r], 63);
     }
-    if (ties != 0ull) {
+    if (!lex && ties != 0ull) {  // (lex: pykeops' order -- ascending (d2, index) -- is the list itself)
       knn_exact_replay(s_cloud, N, k, qx[g], qy[g], qz[g], od, oi);
     } else {
 #pragma unroll
@@ -1237,7 +1237,8 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
                                                                          float* __restrict__ out_d,
                                                                          int64_t* __restrict__ out_i, int M_arg,
                                                                          int N_arg, int k,
-                                                                         const KnnPackPlan* __restrict__ plan, int B) {
+                                                                         const KnnPackPlan* __restrict__ plan, int B,
+                                                                         int lex) {
   __shared__ __align__(16) float tile[TS * 3];
   __shared__ wkey_t hits[kWavesPerBlock][QPW][64];
   const KnnWhere where = knn_where<PACK>(M_arg, N_arg, plan, B);
@@ -1329,7 +1330,7 @@ __global__ __launch_bounds__(kQueryThreads) void knn_points_merge_kernel(const f
     const float below = shr1_fill(d, -1.0f);
     // equal real distances among ranks 0..k -> the heap's mechanics matter
     const unsigned long long ties = __ballot(lane >= 1 && lane <= k && d == below && d < sentinel);
-    if (ties != 0ull) {
+    if (!lex && ties != 0ull) {
       knn_exact_replay_lanes<float, 1>(s_cloud, N, k, qx[g], qy[g], qz[g], od, oi);  // k + 1 <= 64 here
     } else if (lane < k) {
       od[lane] = sqrtf(d);  // :90
@@ -1366,7 +1367,7 @@ __global__ __launch_bounds__(kKgThreads) void knn_points_grid_kernel(const float
                                                                      const float* __restrict__ s,
                                                                      float* __restrict__ out_d,
                                                                      int64_t* __restrict__ out_i, int M, int N, int k,
-                                                                     int G, int QB) {
+                                                                     int G, int QB, int lex) {
   extern __shared__ float4 kg_sorted[];  // N records: x, y, z, index bits -- ordered by cell (x fastest)
   __shared__ int cell_start[kKgMaxCells + 2];
   __shared__ int cursor[kKgMaxCells];
@@ -1658,7 +1659,7 @@ __global__ __launch_bounds__(kKgThreads) void knn_points_grid_kernel(const float
     const float below = shr1_fill(d, -1.0f);
     // equal real distances among ranks 0..k -> the heap's mechanics matter
     const unsigned long long ties = __ballot(lane >= 1 && lane <= k && d == below && d < sentinel);
-    if (ties != 0ull) {
+    if (!lex && ties != 0ull) {
       knn_exact_replay_lanes<float, 1>(s_cloud, N, k, qx, qy, qz, od, oi);
     } else if (lane < k) {
       od[lane] = sqrtf(d);  // :90
@@ -1669,8 +1670,8 @@ __global__ __launch_bounds__(kKgThreads) void knn_points_grid_kernel(const float
 
 template <typename T>
 static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, int N, int k, int device,
-                      void* stream_) {
-  const char* what = "knn_points";
+                      void* stream_, int lex = 0) {
+  const char* what = lex ? "knn (index order)" : "knn_points";
   V3D_REQUIRE(B >= 0 && M >= 0 && N >= 0 && k >= 0, what, "negative dimension");
   if (k > V3D_KNN_MAX_K) {
     set_last_error("%s: num_neighbors=%d exceeds %d (reference: best_dist[100])", what, k, V3D_KNN_MAX_K);
@@ -1713,23 +1714,27 @@ static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, 
       }
       dim3 ggrid((unsigned)ceil_div(M, QB), (unsigned)B);
       hipLaunchKernelGGL(knn_points_grid_kernel, ggrid, dim3(kKgThreads), (size_t)N * sizeof(float4), stream, q, s, od, oi,
-                         M, N, k, G, QB);
+                         M, N, k, G, QB, lex);
       return launch_status(what);
     }
     // batched survivors + bitonic merge: 14-25 % faster than the list from k ~ 24 up, slower below k ~ 12
     if (k >= 24 && k + 1 <= 64) {
-      hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0);
+      hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0, lex);
       return launch_status(what);
     }
   }
   if (k + 1 <= 64)  // the list holds the k+1 best: one or two entries per lane
-    hipLaunchKernelGGL((knn_points_kernel<T, 1, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0);
+    hipLaunchKernelGGL((knn_points_kernel<T, 1, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0, lex);
   else
-    hipLaunchKernelGGL((knn_points_kernel<T, 2, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0);
+    hipLaunchKernelGGL((knn_points_kernel<T, 2, QPW, TS>), grid, block, 0, stream, q, s, od, oi, M, N, k, nullptr, 0, lex);
   return launch_status(what);
 }
 
 constexpr int kKnnPackMaxClouds = 1 << 20;
+static bool knn_pack_uses_cell_list(int B, int64_t total_s, int k) {
+  return k <= kKnnCellListMaxK && B >= 1 && B <= kKnnCellListMaxClouds && total_s / B >= 2048 &&
+         4096ll * B + 4ll * total_s + 1 < (int64_t)INT32_MAX;  // (the cell counters of radius.hip are 32-bit)
+}
 
 static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, const int64_t* s_lengths, float* od,
                     int64_t* oi, int B, int64_t total_q, int64_t total_s, int k, void* workspace,
@@ -1751,10 +1756,16 @@ static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, co
     set_last_error("%s: at most 2^20 clouds, 2^31-1 supports and 2^31-1 queries per call", what);
     return V3D_ERR_SIZE_LIMIT;
   }
+  // Clouds of a few thousand supports and more: the cell list of the radius search (radius.hip) instead of every
+  // (query, support) pair -- 480,000 queries in 30,000-point clouds: 6.0 ms -> see profiles/r03_knn_pack_cell_list.txt.
+  // The host only knows the totals: the average cloud decides.
+  if (knn_pack_uses_cell_list(B, total_s, k))
+    return knn_pack_cell_list(q, s, q_lengths, s_lengths, od, oi, B, total_q, total_s, k, workspace, workspace_bytes, device,
+                              stream_);
   DeviceGuard guard(device);
   if (guard.rc) return guard.rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const size_t need = v3d_knn_pack_workspace_bytes(B);
+  const size_t need = align_up(sizeof(KnnPackPlan) * ((size_t)B + 1), 256);
   void* base = workspace;
   bool own = false;
   if (base == nullptr) {
@@ -1770,13 +1781,13 @@ static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, co
   // every cloud rounds its queries up to whole workgroups: at most one partly filled workgroup per cloud
   dim3 grid((unsigned)(ceil_div(total_q, kPerWg) + B)), block(kQueryThreads);
   if (k >= 24 && k + 1 <= 64)
-    hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS, true>), grid, block, 0, stream, q, s, od, oi, 0, 0, k, plan, B);
+    hipLaunchKernelGGL((knn_points_merge_kernel<QPW, TS, true>), grid, block, 0, stream, q, s, od, oi, 0, 0, k, plan, B, 1);
   else if (k + 1 <= 64)
     hipLaunchKernelGGL((knn_points_kernel<float, 1, QPW, TS, true>), grid, block, 0, stream, q, s, od, oi, 0, 0, k, plan,
-                       B);
+                       B, 1);
   else
     hipLaunchKernelGGL((knn_points_kernel<float, 2, QPW, TS, true>), grid, block, 0, stream, q, s, od, oi, 0, 0, k, plan,
-                       B);
+                       B, 1);
   int rc = launch_status(what);
   if (own) {
     hipError_t e = hipFreeAsync(base, stream);
@@ -1792,8 +1803,10 @@ static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, co
 
 extern "C" {
 
-size_t v3d_knn_pack_workspace_bytes(int B) {
-  return B < 0 ? 0 : v3d::align_up(sizeof(v3d::KnnPackPlan) * ((size_t)B + 1), 256);
+size_t v3d_knn_pack_workspace_bytes(int B, int64_t total_s, int k) {
+  if (B < 0 || total_s < 0) return 0;
+  if (v3d::knn_pack_uses_cell_list(B, total_s, k)) return v3d::knn_pack_cell_list_workspace_bytes(B, total_s);
+  return v3d::align_up(sizeof(v3d::KnnPackPlan) * ((size_t)B + 1), 256);
 }
 
 int v3d_knn_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
@@ -1867,6 +1880,10 @@ int v3d_radius_count_f32(const float* q, const float* s, int64_t* counts, int B,
 int v3d_knn_points_f32(const float* q, const float* s, float* d, int64_t* i, int B, int M, int N, int k, int device,
                        void* stream) {
   return v3d::knn_points<float>(q, s, d, i, B, M, N, k, device, stream);
+}
+int v3d_knn_lex_f32(const float* q, const float* s, float* d, int64_t* i, int B, int M, int N, int k, int device,
+                    void* stream) {
+  return v3d::knn_points<float>(q, s, d, i, B, M, N, k, device, stream, 1);
 }
 int v3d_knn_points_f64(const double* q, const double* s, double* d, int64_t* i, int B, int M, int N, int k, int device,
                        void* stream) {

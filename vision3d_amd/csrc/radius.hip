@@ -30,7 +30,7 @@ namespace v3d {
 
 constexpr int kRsThreads = 256;
 constexpr int kRsMaxDim = 1024;
-constexpr int kRsMaxClouds = 4096;  // plan rows are searched linearly / by bisection per query
+constexpr int kRsMaxClouds = kKnnCellListMaxClouds;  // (4096) plan rows are searched linearly / by bisection per query
 
 struct RsPlan {  // one per cloud
   float ox, oy, oz, inv_h;
@@ -90,13 +90,17 @@ __global__ void rs_bbox_init_kernel(int* __restrict__ bbox, int B) {
 }
 
 // kRsBboxSplit workgroups per cloud: min / max corner of its supports.
+// (lengths that overrun total_s -- device data nobody validated -- are cut like in rs_plan_kernel: no read leaves s)
+__device__ __forceinline__ long long rs_cut(long long len, long long off, long long total) {
+  return len < 0 ? 0 : (len > total - off ? total - off : len);
+}
 __global__ __launch_bounds__(kRsThreads) void rs_bbox_kernel(const float* __restrict__ s, const int64_t* __restrict__ s_len,
-                                                             int* __restrict__ bbox) {
+                                                             int* __restrict__ bbox, long long total_s) {
   __shared__ float red[6][kRsThreads / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   long long off = 0;
-  for (int i = 0; i < b; ++i) off += s_len[i];
-  const long long n = s_len[b];
+  for (int i = 0; i < b; ++i) off += rs_cut(s_len[i], off, total_s);
+  const long long n = rs_cut(s_len[b], off, total_s);
   if ((long long)blockIdx.y * kRsThreads >= n) return;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (long long i = (long long)blockIdx.y * kRsThreads + tid; i < n; i += (long long)kRsThreads * kRsBboxSplit) {
@@ -133,23 +137,42 @@ __device__ __forceinline__ int rs_cell_coord(float p, float o, float inv_h) {
   return (int)fminf(fmaxf(c, -2.0f), (float)(kRsMaxDim + 2));
 }
 
-// One thread: grids, cell offsets and point offsets of all clouds (B is small; everything else waits on this anyway).
-__global__ void rs_plan_kernel(const int* __restrict__ bbox, const int64_t* __restrict__ q_len,
-                               const int64_t* __restrict__ s_len, RsPlan* __restrict__ plan, int* __restrict__ cell_start,
-                               int B, float radius, long long total_s) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  long long s_off = 0, q_off = 0;
-  int cell_off = 0;
-  for (int b = 0; b < B; ++b) {
+// One wave: grids, cell offsets and point offsets of all clouds, 64 clouds at a time (a cloud per lane; the offsets are
+// wave scans with a carry).  Lengths that overrun the totals -- device data nobody validated -- are cut so that no
+// access leaves the arrays: cloud b starts at min(sum of the lengths before it, total) and ends at most at total.
+// per_cell > 0 (kNN): the cell edge comes from the cloud's density instead of a radius -- `per_cell` supports per cell of
+// a cloud spread evenly over its bounding box (axes without extent do not count: a flat cloud gets square cells).
+__device__ __forceinline__ long long rs_wave_inclusive(long long v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__global__ __launch_bounds__(64) void rs_plan_kernel(const int* __restrict__ bbox, const int64_t* __restrict__ q_len,
+                                                     const int64_t* __restrict__ s_len, RsPlan* __restrict__ plan,
+                                                     int B, float radius, long long total_s, long long total_q,
+                                                     float per_cell) {
+  if (blockIdx.x != 0) return;
+  const int lane = threadIdx.x;
+  long long s_carry = 0, q_carry = 0, cell_carry = 0;  // raw (uncut) sums of the lengths / cells before this chunk
+  for (int base = 0; base < B; base += 64) {
+    const int b = base + lane;
+    const bool live = b < B;
+    long long sl = live ? (long long)s_len[b] : 0, ql = live ? (long long)q_len[b] : 0;
+    sl = sl < 0 ? 0 : (sl > total_s ? total_s : sl);  // (also keeps the raw sums far from overflow)
+    ql = ql < 0 ? 0 : (ql > total_q ? total_q : ql);
+    const long long s_end = s_carry + rs_wave_inclusive(sl, lane), q_end = q_carry + rs_wave_inclusive(ql, lane);
     RsPlan p;
-    p.s_off = s_off;
-    p.q_off = q_off;
-    p.s_len = s_len[b];
-    p.q_len = q_len[b];
+    p.s_off = s_end - sl < total_s ? s_end - sl : total_s;
+    p.q_off = q_end - ql < total_q ? q_end - ql : total_q;
+    p.s_len = (s_end < total_s ? s_end : total_s) - p.s_off;
+    p.q_len = (q_end < total_q ? q_end : total_q) - p.q_off;
     p.ox = p.oy = p.oz = 0.f;
     p.inv_h = 1.f;
     p.dx = p.dy = p.dz = 1;
-    if (p.s_len > 0) {
+    if (live && p.s_len > 0) {
       float bb[6];
       for (int a = 0; a < 6; ++a) bb[a] = rs_unordered(bbox[b * 6 + a]);
       p.ox = bb[0];
@@ -157,6 +180,20 @@ __global__ void rs_plan_kernel(const int* __restrict__ bbox, const int64_t* __re
       p.oz = bb[2];
       const long long cap = p.s_len * 4 > 4096 ? p.s_len * 4 : 4096;
       float h = fmaxf(radius, 1e-30f) * 1.001f;
+      if (per_cell > 0.f) {
+        float vol = 1.f;
+        int axes = 0;
+        for (int a = 0; a < 3; ++a) {
+          const float ext = bb[3 + a] - bb[a];
+          if (ext > 0.f && ext < INFINITY) {
+            vol *= ext;
+            ++axes;
+          }
+        }
+        const float per = vol * per_cell / (float)p.s_len;  // volume (area, length) of a cell
+        h = axes == 3 ? cbrtf(per) : (axes == 2 ? sqrtf(per) : (axes == 1 ? per : 1.f));
+        h = (h > 1e-30f && h < INFINITY) ? h : 1.f;  // (overflowing products fall through to the enlarging loop / one cell)
+      }
       for (int it = 0; it < 400; ++it) {
         p.inv_h = 1.0f / h;
         p.dx = rs_cell_coord(bb[3], p.ox, p.inv_h) + 1;
@@ -178,13 +215,14 @@ __global__ void rs_plan_kernel(const int* __restrict__ bbox, const int64_t* __re
         p.dx = p.dy = p.dz = 1;
       }
     }
-    p.cell_off = cell_off;
-    plan[b] = p;
-    cell_off += p.dx * p.dy * p.dz;
-    s_off += p.s_len;
-    q_off += p.q_len;
+    const long long cells = live ? (long long)p.dx * p.dy * p.dz : 0;
+    const long long cell_end = cell_carry + rs_wave_inclusive(cells, lane);
+    p.cell_off = (int)(cell_end - cells);  // < 2^31: rs_run refuses sizes whose cell capacity does not fit
+    if (live) plan[b] = p;
+    s_carry = __shfl(s_end, 63, 64);
+    q_carry = __shfl(q_end, 63, 64);
+    cell_carry = __shfl(cell_end, 63, 64);
   }
-  (void)cell_start;  // the scan over the whole counter array also writes the end of the last cloud's last cell
 }
 
 __device__ __forceinline__ int rs_find_cloud(const RsPlan* __restrict__ plan, int B, long long i, bool query) {
@@ -464,6 +502,278 @@ __global__ __launch_bounds__(kRsThreads) void rs_count_query_kernel(const float*
   if (lane == 0) counts[qi] = (int64_t)cnt;
 }
 
+
+// ---- pack-mode kNN on the same cell list (ops/knn.py:110-145; launched by knn_pack_cell_list below) -------------------
+// k nearest supports of the query's own cloud, ascending by (d2, support index) -- the order pykeops' Kmin_argKmin leaves
+// (strict-< insertion while scanning the supports in index order), which is also the radius search's.  One WAVE per
+// query.  The 27 cells around the query are 9 runs of consecutive records; a first walk keeps every lane's minimum
+// distance (the first 64 records of every run stay in registers), the k-th smallest of the 64 minima bounds the k-th
+// distance from above, and only candidates under it are batched as 64-bit keys and sorted (wave_rank_sort / the bitonic
+// merge of wave_sort.h).  The search is exact: the k-th distance is compared with the distance to the nearest face of
+// the explored box that still has cells behind it (minus a rounding margin) and the box grows ring by ring -- the
+// bounds of a ring's rows fetched by the lanes in one round trip -- until it is below; a query that is still not done
+// after kKpMaxRing rings (far from its cloud, or a cloud of distant clusters) scans its cloud's records linearly.
+constexpr int kKpMaxRing = 6;
+static float kp_supports_per_cell(int k) { return std::max(12.0f, 0.36f * (float)k); }
+
+__device__ __forceinline__ float kp_sq_dist(float qx, float qy, float qz, float sx, float sy, float sz) {
+  const float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+  return (dx * dx + dy * dy) + dz * dz;  // reference order, one rounding per operation (-ffp-contract=off)
+}
+// (k+1)-th smallest (k = 0..63) of the lanes' non-negative values, rounded up at bit 17 of the pattern (<= 1.6 % above;
+// 14 ballots); +inf when fewer than k+1 lanes hold a finite value.  (query.hip's kth_smallest_upper.)
+__device__ __forceinline__ float kp_kth_upper(float v, int k) {
+  const unsigned bits = __float_as_uint(v);
+  unsigned prefix = 0;
+  for (int b = 30; b >= 17; --b) {
+    const unsigned trial = prefix | (1u << b);
+    if (__builtin_popcountll(__ballot(bits < trial)) <= k) prefix = trial;
+  }
+  return __uint_as_float(prefix | 0x1ffffu);
+}
+
+__device__ __forceinline__ wkey_t kp_wave_min64(wkey_t v) {  // minimum over the lanes, in every lane
+#pragma unroll
+  for (int j = 1; j < 64; j <<= 1) {
+    const wkey_t o = wave_xor64(v, j);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// NS = cells per axis of the first box: 3 (the cell of the query and its neighbours, 9 runs of 3 cells) or, for k <= 3,
+// 2 (per axis the query's cell and the neighbour on the side of the query: the 8 cells nearest to it, 4 runs of 2 cells
+// -- at >= 12 supports per cell the third neighbour of a uniform cloud lies within 0.4 cell edges, the nearest face of
+// that box at >= 0.5).
+template <int NS>
+__global__ __launch_bounds__(kRsThreads) void kp_query_kernel(const float* __restrict__ q, const RsPlan* __restrict__ plan,
+                                                              const int* __restrict__ cell_start,
+                                                              const float4* __restrict__ sorted,
+                                                              float* __restrict__ out_d, int64_t* __restrict__ out_i,
+                                                              int B, long long total_q, int k) {
+  constexpr int NR = NS * NS;
+  __shared__ wkey_t hits[kRsThreads / 64][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long qi = (long long)blockIdx.x * (kRsThreads / 64) + wave;
+  if (qi >= total_q) return;
+  const float qx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[qi * 3])));
+  const float qy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[qi * 3 + 1])));
+  const float qz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[qi * 3 + 2])));
+  const RsPlan p = plan[rs_find_query_cloud(plan, B, qi, lane)];
+  const float sentinel = 1e10f;  // as v3d_knn_points_f32: nothing at or beyond 1e10 enters; unfilled slots read (1e5, 0)
+  const wkey_t sent_key = (wkey_t)__float_as_uint(sentinel) << 32;
+  wkey_t* buf = hits[wave];
+  wkey_t kept = sent_key, worst = sent_key;
+  int pending = 0;
+  bool kept_empty = true;
+  auto offer_key = [&](wkey_t key, bool take) {
+    const unsigned long long m = __ballot(take);
+    if (m == 0ull) return;
+    const int n = __builtin_popcountll(m);
+    const int dest = pending + wave_prefix_count(m);
+    if (take && dest < 64) buf[dest] = key;
+    if (pending + n >= 64) {
+      kept = wave_merge_buffer(kept, buf, 64, lane);
+      kept_empty = false;
+      worst = wave_lane64(kept, k - 1);
+      if (take && dest >= 64) buf[dest - 64] = key;
+      pending += n - 64;
+    } else {
+      pending += n;
+    }
+  };
+  auto offer = [&](int j, bool valid, float cap) {  // record j (lane-varying) of the sorted list
+    const float4 s = sorted[valid ? j : 0];
+    const float d = kp_sq_dist(qx, qy, qz, s.x, s.y, s.z);
+    const wkey_t key = ((wkey_t)__float_as_uint(d) << 32) | (unsigned)__float_as_int(s.w);
+    offer_key(key, valid && key < worst && d <= cap);  // NaN / +inf patterns lie above the sentinel's
+  };
+  auto flush = [&]() {
+    if (pending > 0) {
+      if (kept_empty) {
+        const wkey_t h = wave_rank_sort(buf, pending, lane);
+        kept = h < sent_key ? h : sent_key;
+      } else {
+        kept = wave_merge_buffer(kept, buf, pending, lane);
+      }
+      kept_empty = false;
+      worst = wave_lane64(kept, k - 1);
+      pending = 0;
+    }
+  };
+  if (p.s_len > 0) {
+    const int dim[3] = {p.dx, p.dy, p.dz};
+    const float org[3] = {p.ox, p.oy, p.oz}, qv[3] = {qx, qy, qz};
+    int p0[3], p1[3];  // the explored box of cells
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float t = (qv[a] - org[a]) * p.inv_h;  // rs_cell_coord's expression
+      const int cc = min(max(rs_cell_coord(qv[a], org[a], p.inv_h), 0), dim[a] - 1);
+      int lo;
+      if (NS == 3) {
+        lo = max(cc - 1, 0);
+        p1[a] = min(cc + 1, dim[a] - 1);
+      } else {
+        lo = max(min(cc - ((t - floorf(t)) < 0.5f ? 1 : 0), dim[a] - 2), 0);  // (which side only matters for speed)
+        p1[a] = min(lo + 1, dim[a] - 1);
+      }
+      p0[a] = __builtin_amdgcn_readfirstlane(lo);
+      p1[a] = __builtin_amdgcn_readfirstlane(p1[a]);
+    }
+    {  // ---- the first box: NR runs of consecutive records
+      int rb = 0, rn = 0;
+      if (lane < NR) {
+        const int zz = p0[2] + lane / NS, yy = p0[1] + lane % NS;
+        if (zz <= p1[2] && yy <= p1[1]) {
+          const int c0 = p.cell_off + (zz * p.dy + yy) * p.dx;
+          rb = cell_start[c0 + p0[0]];
+          rn = cell_start[c0 + p1[0] + 1] - rb;
+        }
+      }
+      int beg[NR], len[NR], pre = 0;
+      float dr[NR];
+      unsigned wr[NR];
+      float lmin = INFINITY;
+      bool long_run = false;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        beg[r] = __builtin_amdgcn_readlane(rb, r);
+        len[r] = __builtin_amdgcn_readlane(rn, r);
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        // run r is dealt to the lanes from lane (records before it) mod 64 on, as if the runs were concatenated
+        const int jr = (lane - pre) & 63;
+        const bool valid = jr < len[r];
+        const float4 s = sorted[valid ? beg[r] + jr : 0];
+        const float d = kp_sq_dist(qx, qy, qz, s.x, s.y, s.z);
+        dr[r] = valid ? d : __uint_as_float(0x7fc00000u);  // an idle lane's entry never passes a comparison
+        wr[r] = (unsigned)__float_as_int(s.w);
+        lmin = (valid && d < lmin) ? d : lmin;  // +inf and NaN never replace a minimum
+        for (int j = 64; j < len[r]; j += 64) {  // (a crowded run: more than 64 records)
+          const int jj = j + jr;
+          const float4 s2 = sorted[jj < len[r] ? beg[r] + jj : 0];
+          const float d2 = kp_sq_dist(qx, qy, qz, s2.x, s2.y, s2.z);
+          lmin = (jj < len[r] && d2 < lmin) ? d2 : lmin;
+          long_run = true;
+        }
+        pre += len[r];
+      }
+      if (k == 1 && !long_run) {
+        // the nearest one: every lane's smallest key, then the wave's -- no bound, no batch, no sort
+        wkey_t best = kWaveKeyMax;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const wkey_t key = ((wkey_t)__float_as_uint(dr[r]) << 32) | wr[r];
+          best = key < best ? key : best;
+        }
+        best = kp_wave_min64(best);
+        worst = best < sent_key ? best : sent_key;
+        kept = lane == 0 ? worst : sent_key;
+        kept_empty = false;
+      } else {
+        const float capk = pre > 64 ? kp_kth_upper(lmin, k - 1) : INFINITY;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const wkey_t key = ((wkey_t)__float_as_uint(dr[r]) << 32) | wr[r];
+          offer_key(key, key < worst && dr[r] <= capk);
+        }
+        if (long_run) {
+          int pre2 = 0;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int jr = (lane - pre2) & 63;
+            for (int j = 64; j < len[r]; j += 64) offer(beg[r] + j + jr, j + jr < len[r], capk);
+            pre2 += len[r];
+          }
+        }
+      }
+    }
+    // ---- one more layer of cells around the box at a time, until the k-th distance lies inside it
+    const float hc = 1.0f / p.inv_h;  // (inv_h = 0: the one-cell grid of a cloud without a finite box; never `open`)
+    for (int ring = 1;; ++ring) {
+      flush();  // the bound below needs the true k-th key
+      float bound = INFINITY;
+      bool open = false;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float rel = qv[a] - org[a];
+        const float margin = 1e-5f * fmaxf((float)dim[a] * hc, fabsf(rel));
+        if (p0[a] > 0) {
+          open = true;
+          bound = fminf(bound, fmaxf(rel - (float)p0[a] * hc - margin, 0.f));
+        }
+        if (p1[a] < dim[a] - 1) {
+          open = true;
+          bound = fminf(bound, fmaxf((float)(p1[a] + 1) * hc - rel - margin, 0.f));
+        }
+      }
+      const float dk = __uint_as_float((unsigned)(worst >> 32));
+      if (!open || dk < bound * bound) break;  // (NaN bounds compare false: the search goes on to the whole cloud)
+      if (ring > kKpMaxRing) {
+        // start over on the whole cloud, admitting only what is at most as far as the k-th found so far
+        kept = worst = sent_key;
+        kept_empty = true;
+        for (long long j0 = p.s_off; j0 < p.s_off + p.s_len; j0 += 64)
+          offer((int)(j0 + lane), j0 + lane < p.s_off + p.s_len, dk);
+        flush();
+        break;
+      }
+      int r0[3], r1[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        r0[a] = max(p0[a] - 1, 0);
+        r1[a] = min(p1[a] + 1, dim[a] - 1);
+      }
+      // rows (z, y) of the grown box, 64 at a time: lane l fetches the bounds of row l -- the whole row outside the
+      // explored box's (z, y) range, else the part left and the part right of it
+      const int ny = r1[1] - r0[1] + 1, rows = (r1[2] - r0[2] + 1) * ny;
+      for (int base = 0; base < rows; base += 64) {
+        const int row = base + lane;
+        int b0 = 0, n0 = 0, b1 = 0, n1 = 0;
+        if (row < rows) {
+          const int z = r0[2] + row / ny, y = r0[1] + row % ny;
+          const int c0 = p.cell_off + (z * p.dy + y) * p.dx;
+          const bool inner = z >= p0[2] && z <= p1[2] && y >= p0[1] && y <= p1[1];
+          if (!inner) {
+            b0 = cell_start[c0 + r0[0]];
+            n0 = cell_start[c0 + r1[0] + 1] - b0;
+          } else {
+            if (r0[0] < p0[0]) {
+              b0 = cell_start[c0 + r0[0]];
+              n0 = cell_start[c0 + p0[0]] - b0;
+            }
+            if (r1[0] > p1[0]) {
+              b1 = cell_start[c0 + p1[0] + 1];
+              n1 = cell_start[c0 + r1[0] + 1] - b1;
+            }
+          }
+        }
+        unsigned long long busy = __ballot(n0 > 0 || n1 > 0);
+        while (busy) {
+          const int l = __builtin_ffsll((long long)busy) - 1;
+          busy &= busy - 1ull;
+          const int sb0 = __builtin_amdgcn_readlane(b0, l), sn0 = __builtin_amdgcn_readlane(n0, l);
+          const int sb1 = __builtin_amdgcn_readlane(b1, l), sn1 = __builtin_amdgcn_readlane(n1, l);
+          for (int j = 0; j < sn0; j += 64) offer(sb0 + j + lane, j + lane < sn0, INFINITY);
+          for (int j = 0; j < sn1; j += 64) offer(sb1 + j + lane, j + lane < sn1, INFINITY);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        p0[a] = r0[a];
+        p1[a] = r1[a];
+      }
+    }
+  }
+  if (lane < k) {
+    const bool real = kept < sent_key;
+    out_d[qi * k + lane] = sqrtf(__uint_as_float((unsigned)(kept >> 32)));
+    out_i[qi * k + lane] = real ? (int64_t)(unsigned)kept - (int64_t)p.s_off : 0;
+  }
+}
+
 }  // namespace v3d
 
 extern "C" {
@@ -476,11 +786,14 @@ size_t v3d_radius_search_workspace_bytes(int B, int64_t total_s) {
 }  // extern "C"
 
 namespace v3d {
-// neighbor_limit < 0: count mode (`out` = counts (total_q,)), else search mode (`out` = neighbor_indices)
+// neighbor_limit < 0: count mode (`out` = counts (total_q,)), else search mode (`out` = neighbor_indices);
+// knn_distances != nullptr: kNN mode (neighbor_limit = k <= 64, radius unused, cells sized by density)
 static int rs_run(const char* what, const float* q_points, const float* s_points, const int64_t* q_lengths,
                   const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q, int64_t total_s,
-                  float radius, int neighbor_limit, void* workspace, size_t workspace_bytes, int device, void* stream_) {
+                  float radius, int neighbor_limit, void* workspace, size_t workspace_bytes, int device, void* stream_,
+                  float* knn_distances = nullptr) {
   const bool count_mode = neighbor_limit < 0;
+  const float per_cell = knn_distances ? kp_supports_per_cell(neighbor_limit) : 0.f;
   V3D_REQUIRE(B >= 0 && total_q >= 0 && total_s >= 0, what, "negative dimension");
   if (total_q == 0 || neighbor_limit == 0) return 0;
   V3D_REQUIRE(B > 0, what, "points without clouds");
@@ -491,9 +804,10 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
     set_last_error("%s: neighbor_limit=%d exceeds %d", what, neighbor_limit, V3D_RADIUS_MAX_LIMIT);
     return V3D_ERR_K_TOO_LARGE;
   }
-  if (B > kRsMaxClouds || total_s >= (int64_t)INT32_MAX - 1 ||
+  if (B > kRsMaxClouds || rs_cell_capacity(B, total_s) >= (int64_t)INT32_MAX ||
       ceil_div(total_q, kRsThreads / 64) > (int64_t)INT32_MAX) {
-    set_last_error("%s: at most %d clouds, 2^31-2 supports and 2^33 queries per call", what, kRsMaxClouds);
+    set_last_error("%s: at most %d clouds, ~2^29 supports (4096 B + 4 total_s < 2^31 cells) and 2^33 queries per call",
+                   what, kRsMaxClouds);
     return V3D_ERR_SIZE_LIMIT;
   }
   DeviceGuard guard(device);
@@ -520,9 +834,10 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
     }
     hipLaunchKernelGGL(rs_bbox_init_kernel, dim3((unsigned)ceil_div((int64_t)B * 6, 256)), dim3(256), 0, stream, ws.bbox,
                        B);
-    hipLaunchKernelGGL(rs_bbox_kernel, dim3(B, kRsBboxSplit), dim3(kRsThreads), 0, stream, s_points, s_lengths, ws.bbox);
-    hipLaunchKernelGGL(rs_plan_kernel, dim3(1), dim3(64), 0, stream, ws.bbox, q_lengths, s_lengths, ws.plan,
-                       ws.cell_start, B, radius, (long long)total_s);
+    hipLaunchKernelGGL(rs_bbox_kernel, dim3(B, kRsBboxSplit), dim3(kRsThreads), 0, stream, s_points, s_lengths, ws.bbox,
+                       (long long)total_s);
+    hipLaunchKernelGGL(rs_plan_kernel, dim3(1), dim3(64), 0, stream, ws.bbox, q_lengths, s_lengths, ws.plan, B, radius,
+                       (long long)total_s, (long long)total_q, per_cell);
     const size_t cap = (size_t)rs_cell_capacity(B, total_s);
     if (total_s > 0) {
       const unsigned sb = (unsigned)ceil_div(total_s, kRsThreads);
@@ -543,7 +858,13 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
                          ws.cell_count, ws.sorted, B, (long long)total_s);
     }
     const unsigned qb = (unsigned)ceil_div(total_q, kRsThreads / 64);
-    if (count_mode)
+    if (knn_distances && neighbor_limit <= 3)
+      hipLaunchKernelGGL(kp_query_kernel<2>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
+                         ws.sorted, knn_distances, neighbor_indices, B, (long long)total_q, neighbor_limit);
+    else if (knn_distances)
+      hipLaunchKernelGGL(kp_query_kernel<3>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
+                         ws.sorted, knn_distances, neighbor_indices, B, (long long)total_q, neighbor_limit);
+    else if (count_mode)
       hipLaunchKernelGGL(rs_count_query_kernel, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
                          ws.sorted, neighbor_indices, B, (long long)total_q, radius);
     else if (neighbor_limit <= 64)
@@ -573,6 +894,14 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
   }
   return rc;
 }
+// Pack-mode kNN on the cell list (declared in common.h, called by query.hip's knn_pack): k <= 64.
+int knn_pack_cell_list(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
+                       float* distances, int64_t* indices, int B, int64_t total_q, int64_t total_s, int k,
+                       void* workspace, size_t workspace_bytes, int device, void* stream) {
+  return rs_run("knn_pack_mode", q_points, s_points, q_lengths, s_lengths, indices, B, total_q, total_s, 0.f, k,
+                workspace, workspace_bytes, device, stream, distances);
+}
+size_t knn_pack_cell_list_workspace_bytes(int B, int64_t total_s) { return rs_carve(nullptr, B, total_s).bytes; }
 }  // namespace v3d
 
 extern "C" {

@@ -467,9 +467,28 @@ def radius_search_pack(q_points, s_points, q_lengths, s_lengths, neighbor_indice
     _lib.check(rc, "radius_search_pack_mode")
 
 
+def knn_lex(q_points, s_points, knn_distances, knn_indices, num_neighbors):
+    """q_points (B,M,3), s_points (B,N,3) fp32 -> knn_distances (B,M,k) ascending, knn_indices (B,M,k) int64; equal
+    distances lower index first (the order pykeops' Kmin_argKmin yields; ``knn_points`` keeps the CUDA heap's)."""
+    for t, name in ((q_points, "q_points"), (s_points, "s_points"), (knn_distances, "knn_distances"),
+                    (knn_indices, "knn_indices")):
+        _check_cuda_contiguous(t, name)
+    for t, name in ((q_points, "q_points"), (s_points, "s_points"), (knn_distances, "knn_distances")):
+        _check_float(t, name)
+    _check_long(knn_indices, "knn_indices")
+    B, M, N, k = q_points.size(0), q_points.size(1), s_points.size(1), int(num_neighbors)
+    if q_points.size(-1) != 3 or s_points.size(-1) != 3 or s_points.size(0) != B:
+        raise RuntimeError("knn_lex: points must be (B, M, 3) and (B, N, 3)")
+    if knn_distances.numel() != B * M * k or knn_indices.numel() != B * M * k:
+        raise RuntimeError("knn_lex: distances / indices must hold k entries per query")
+    dev, stream = _where(q_points)
+    _lib.check(_lib.lib().v3d_knn_lex_f32(q_points.data_ptr(), s_points.data_ptr(), knn_distances.data_ptr(),
+                                         knn_indices.data_ptr(), B, M, N, k, dev, stream), "knn")
+
+
 def knn_pack(q_points, s_points, q_lengths, s_lengths, distances, indices, num_neighbors):
     """q_points (M,3), s_points (N,3) fp32; lengths (B,) int64 on the same device -> distances (M,k) fp32, indices (M,k)
-    int64 = positions inside the query's own cloud.  k <= 100 (the knn_points kernels)."""
+    int64 = positions inside the query's own cloud, equal distances lower index first (pykeops' order).  k <= 100."""
     for t, name in ((q_points, "q_points"), (s_points, "s_points"), (q_lengths, "q_lengths"), (s_lengths, "s_lengths"),
                     (distances, "distances"), (indices, "indices")):
         _check_cuda_contiguous(t, name)
@@ -486,7 +505,7 @@ def knn_pack(q_points, s_points, q_lengths, s_lengths, distances, indices, num_n
     if distances.numel() != M * k or indices.numel() != M * k:
         raise RuntimeError("knn_pack: distances / indices must hold k entries per query")
     dev, stream = _where(q_points)
-    ws = _workspace(_lib.lib().v3d_knn_pack_workspace_bytes(B), q_points)
+    ws = _workspace(_lib.lib().v3d_knn_pack_workspace_bytes(B, N, k), q_points)
     rc = _lib.lib().v3d_knn_pack_f32(
         q_points.data_ptr(), s_points.data_ptr(), q_lengths.data_ptr(), s_lengths.data_ptr(), distances.data_ptr(),
         indices.data_ptr(), B, M, N, k, ws.data_ptr(), ws.numel(), dev, stream)

@@ -4,10 +4,14 @@ The reference delegates the search to pykeops (``keops_knn``, knn.py:10-27: k sm
 ascending, with their indices).  pykeops is a third-party JIT library absent from this build, so the search is
 re-backed by our own kernels:
 
-* 3-D fp32/fp64 points, k <= 100: the exact-difference ``knn_points`` kernels;
+* 3-D fp32 points, k <= 100: the exact-difference ``knn_points`` kernels without their heap replay (``ext.knn_lex``);
 * any other channel count or larger k (<= 2048): MFMA distances + row selection + exact re-ranking (``ext.knn_feat``);
-* pack mode (3-D fp32, k <= 100): the same ``knn_points`` kernels working on each cloud's own slice of the packed arrays
-  (``ext.knn_pack``) -- no padded batch, no ``.item()``.
+* pack mode (3-D fp32, k <= 100): the radius search's cell list for clouds of a few thousand points and more, the
+  ``knn_points`` kernels on each cloud's own slice of the packed arrays below (``ext.knn_pack``) -- no padded batch, no
+  ``.item()``.
+
+Equal distances come lower index first on every route: pykeops' ``Kmin_argKmin`` inserts with a strict ``<`` while it
+scans the supports in index order (``ops.knn_points``, the reference's CUDA kernel, keeps ITS order: a max-heap's).
 
 ``knn``'s options (dilation, remove_nearest, distance_limit / padding_mode, squeeze; reference knn.py:43-63) are expressed
 as ONE strided column selection of the ascending list plus one masked fill.
@@ -42,7 +46,7 @@ def keops_knn(q_points: Tensor, s_points: Tensor, k: int) -> Tuple[Tensor, Tenso
     dist = qb.new_empty((qb.shape[0], n, k))
     idx = torch.empty((qb.shape[0], n, k), dtype=torch.long, device=qb.device)
     if c == 3 and k <= _KNN_POINTS_MAX_K:
-        ext.knn_points(qb, sb, dist, idx, k)
+        ext.knn_lex(qb, sb, dist, idx, k)
     else:
         ext.knn_feat(qb, sb, dist, idx, k)
     return dist.reshape(lead + (n, k)), idx.reshape(lead + (n, k))
