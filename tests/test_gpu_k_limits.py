@@ -383,6 +383,25 @@ def test_knn_lex_index_order_vs_oracle(ext, oracle_mod, name):
         oracle_mod.set_threads(1)
 
 
+def test_ops_knn_large_3d_clouds_take_the_cell_list_and_agree_with_the_batch_kernels(ext):
+    """ops.knn on 3-D clouds beyond the batch kernels' LDS cell list (> 4096 supports) runs the pack-mode cell list with
+    every cloud as one cloud of a pack: identical to v3d_knn_lex_f32 (pair by pair) on the same inputs."""
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    q = torch.rand((2, 3000, 3), generator=g).to(DEV)
+    s = torch.rand((2, 9000, 3), generator=g).to(DEV)
+    s[1, 100:200] = s[1, :100]  # duplicates: equal distances
+    for k in (1, 3, 20):
+        d, i = ops.knn(q, s, k, return_distance=True)
+        wd = torch.empty_like(d)
+        wi = torch.empty_like(i)
+        ext.knn_lex(q, s, wd, wi, k)
+        assert torch.equal(i, wi) and torch.equal(d, wd)
+    # unbatched (N, 3) inputs
+    assert torch.equal(ops.knn(q[0], s[0], 5), ops.knn(q[:1], s[:1], 5)[0])
+
+
 def test_knn_pack_mode_op_matches_padded_route_and_keeps_the_assertion(ext, oracle_mod):
     from vision3d_amd import ops
 

@@ -142,6 +142,16 @@ def main():
         ki = torch.empty((nc * nq, k), dtype=torch.long, device=DEV)
         add(f"knn_pack clouds{nc} q{nq} s{ns} k{k}",
             lambda qp=qp, sp=sp, ql=ql, sl=sl, kd=kd, ki=ki, k=k: ext.knn_pack(qp, sp, ql, sl, kd, ki, k), nc * nq, "Mq/s")
+    # ops.knn on large 3-D clouds (single cloud, superpoint <- point style): pack cell list vs the batch kernels
+    from vision3d_amd import ops as _ops
+    for (nq, ns, k) in ((100000, 12500, 1), (12500, 100000, 16), (100000, 100000, 16)):
+        qp = torch.rand((nq, 3), generator=g).to(DEV)
+        sp = torch.rand((ns, 3), generator=g).to(DEV)
+        kd = torch.empty((1, nq, k), device=DEV)
+        ki = torch.empty((1, nq, k), dtype=torch.long, device=DEV)
+        add(f"knn3d ops.knn q{nq} s{ns} k{k}", lambda qp=qp, sp=sp, k=k: _ops.knn(qp, sp, k), nq, "Mq/s")
+        add(f"knn3d knn_lex (batch kernels) q{nq} s{ns} k{k}",
+            lambda qp=qp, sp=sp, kd=kd, ki=ki, k=k: ext.knn_lex(qp[None], sp[None], kd, ki, k), nq, "Mq/s")
     for (nc, n, vs) in ((16, 30000, 0.025), (16, 30000, 0.1)):
         pts = (torch.rand((nc * n, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(DEV)
         lengths = torch.full((nc,), n, dtype=torch.long, device=DEV)

@@ -26,6 +26,9 @@ from .conversion import batch_to_pack, pack_to_batch
 
 _KNN_POINTS_MAX_K = 100  # knn_points_cuda.cuh:68 (best_dist[100]); kept by our kernels
 _KNN_FEAT_MAX_K = 2048  # include/v3d_hip.h: V3D_KNN_FEAT_MAX_K
+_KNN_CELL_LIST_MAX_K = 64  # v3d_knn_pack_f32: the cell-list route (k <= 64, <= 4096 clouds, >= 2048 supports per cloud)
+_KNN_CELL_LIST_MAX_CLOUDS = 4096
+_KNN_LDS_MAX_SUPPORTS = 4096  # up to here v3d_knn_lex_f32 builds its cell list per workgroup in LDS
 
 
 def keops_knn(q_points: Tensor, s_points: Tensor, k: int) -> Tuple[Tensor, Tensor]:
@@ -45,7 +48,13 @@ def keops_knn(q_points: Tensor, s_points: Tensor, k: int) -> Tuple[Tensor, Tenso
     sb = s_points.reshape((-1, m, c)).contiguous()
     dist = qb.new_empty((qb.shape[0], n, k))
     idx = torch.empty((qb.shape[0], n, k), dtype=torch.long, device=qb.device)
-    if c == 3 and k <= _KNN_POINTS_MAX_K:
+    if c == 3 and k <= _KNN_CELL_LIST_MAX_K and m > _KNN_LDS_MAX_SUPPORTS and qb.shape[0] <= _KNN_CELL_LIST_MAX_CLOUDS:
+        # clouds too large for the per-workgroup cell list of the batch kernels: the pack-mode cell list, every cloud
+        # of the batch one cloud of a pack with equal lengths (same order among equal distances)
+        ql = torch.full((qb.shape[0],), n, dtype=torch.long, device=qb.device)
+        sl = torch.full((qb.shape[0],), m, dtype=torch.long, device=qb.device)
+        ext.knn_pack(qb.reshape(-1, 3), sb.reshape(-1, 3), ql, sl, dist.reshape(-1, k), idx.reshape(-1, k), k)
+    elif c == 3 and k <= _KNN_POINTS_MAX_K:
         ext.knn_lex(qb, sb, dist, idx, k)
     else:
         ext.knn_feat(qb, sb, dist, idx, k)
