@@ -217,6 +217,19 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
                                const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q,
                                int64_t total_s, float radius, int neighbor_limit, void* workspace,
                                size_t workspace_bytes, int device, void* stream);
+/* The same search with the cell list held by the caller: built once, searched by several query sets.  The pyramid
+ * builder (models/graph_pyramid/graph_pyramid.py:31-45) searches the points of one level three times at one radius --
+ * its neighbours, the subsampling of the level below into it, the upsampling of the level above -- and the reference
+ * re-pads and re-searches each time (ops/radius_search.py:44-71); here the counting sort of the supports is shared.
+ * v3d_radius_grid_build_f32 leaves in `grid` (v3d_radius_search_workspace_bytes(B, total_s) bytes, caller-owned, 256-B
+ * aligned) a cell list that serves every radius <= cell_radius; v3d_radius_search_grid_f32 is
+ * v3d_radius_search_pack_f32 on it -- identical result -- and takes the B, total_s and cell_radius of the build.
+ * Searches on one grid must be ordered among themselves (each rewrites the query offsets kept in it). */
+int v3d_radius_grid_build_f32(const float* s_points, const int64_t* s_lengths, int B, int64_t total_s, float cell_radius,
+                              void* grid, size_t grid_bytes, int device, void* stream);
+int v3d_radius_search_grid_f32(const float* q_points, const int64_t* q_lengths, int64_t* neighbor_indices, int B,
+                               int64_t total_q, int64_t total_s, float cell_radius, float radius, int neighbor_limit,
+                               void* grid, size_t grid_bytes, int device, void* stream);
 /* Pack-mode kNN, replaces vision3d/ops/knn.py:110-145 (pack -> batch padded with points at 1e10 -> pykeops kNN -> pack):
  * for every query the k nearest supports of ITS OWN cloud: distances (total_q,k) = sqrt of the squared distance,
  * ascending; indices (total_q,k) i64 = positions inside the cloud (what the reference's padded batch yields).  Equal

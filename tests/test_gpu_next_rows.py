@@ -1102,3 +1102,46 @@ def test_next_row_entry_points_take_caller_owned_workspaces():
                                                          osc2.data_ptr(), num.data_ptr(), cap, p, n, dev, stream),
              lambda: [orow2, ocol2, osc2, num])
     assert lib.v3d_threshold_select_workspace_bytes(100, 100) == 0  # one-launch size: no scratch at all
+
+
+def test_radius_grid_built_once_serves_several_query_sets_and_radii(ext, oracle_mod):
+    """v3d_radius_grid_build_f32 + v3d_radius_search_grid_f32: one cell list of the supports, searched by two query sets
+    and at two radii up to the one it was built for -- every table identical to a search of its own and to the oracle."""
+    rng = np.random.default_rng(5)
+    sl = np.asarray([900, 0, 1500, 40], np.int64)
+    s = rng.random((int(sl.sum()), 3), dtype=np.float32)
+    qsets = [(s, sl), (rng.random((700, 3), dtype=np.float32), np.asarray([300, 50, 349, 1], np.int64))]
+    ts, tsl = T(s), T(sl)
+    grid = ext.radius_grid_build(ts, tsl, 0.2)
+    for q, ql in qsets:
+        for radius, limit in ((0.2, 40), (0.1, 16), (0.2, 100), (0.0, 3)):
+            out = torch.full((q.shape[0], limit), -1, dtype=torch.long, device=DEV)
+            ext.radius_search_grid(T(q), T(ql), grid, out, radius, limit)
+            own = torch.full_like(out, -2)
+            ext.radius_search_pack(T(q), ts, T(ql), tsl, own, radius, limit)
+            assert torch.equal(out, own), (radius, limit)
+            assert np.array_equal(N_(out), oracle_mod.radius_search_pack(q, s, ql, sl, radius, limit)), (radius, limit)
+    out = torch.zeros((700, 8), dtype=torch.long, device=DEV)
+    with pytest.raises(RuntimeError, match="beyond the radius the grid was built for"):
+        ext.radius_search_grid(T(qsets[1][0]), T(qsets[1][1]), grid, out, 0.25, 8)
+
+
+def test_graph_pyramid_tables_equal_table_by_table_searches(ext):
+    """ops.build_grid_and_radius_graph_pyramid shares one cell list per stage among its searches
+    (graph_pyramid.py:31-45 searches table by table): the tables are those of searches of their own."""
+    from vision3d_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    lengths = torch.tensor([4000, 2500, 6000], device=DEV)
+    pts = (torch.rand((int(lengths.sum()), 3), generator=g) * torch.tensor([2.0, 2.0, 1.0])).to(DEV)
+    limits = [24, 20, 18]
+    pyr = ops.build_grid_and_radius_graph_pyramid(pts, lengths, 3, 0.05, 0.12, limits)
+    radius = 0.12
+    for i in range(3):
+        cp, cl = pyr["points"][i], pyr["lengths"][i]
+        assert torch.equal(pyr["neighbors"][i], ops.radius_search_pack_mode(cp, cp, cl, cl, radius, limits[i]))
+        if i < 2:
+            sp, sl = pyr["points"][i + 1], pyr["lengths"][i + 1]
+            assert torch.equal(pyr["subsampling"][i], ops.radius_search_pack_mode(sp, cp, sl, cl, radius, limits[i]))
+            assert torch.equal(pyr["upsampling"][i], ops.radius_search_pack_mode(cp, sp, cl, sl, radius * 2, limits[i + 1]))
+        radius *= 2

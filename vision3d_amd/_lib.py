@@ -75,6 +75,9 @@ SIGNATURES = {
     "v3d_radius_search_workspace_bytes": (_c_size, [_c_int, _c_i64]),
     "v3d_radius_search_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32, _c_int] + _WS + _TAIL),
+    "v3d_radius_grid_build_f32": (_c_int, [_c_ptr, _c_ptr, _c_int, _c_i64, _c_f32] + _WS + _TAIL),
+    "v3d_radius_search_grid_f32": (
+        _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_int] + _WS + _TAIL),
     "v3d_knn_pack_workspace_bytes": (_c_size, [_c_int, _c_i64, _c_int]),
     "v3d_knn_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_int] + _WS + _TAIL),

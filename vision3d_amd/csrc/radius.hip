@@ -19,6 +19,8 @@
 //                          The result does not depend on the order candidates arrive in.
 // Distances use the reference expression order (dx*dx + dy*dy) + dz*dz with one rounding per operation.
 #include <algorithm>
+#include <cfloat>
+#include <cmath>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64) void rs_plan_kernel(const int* __restrict__ bbo
   for (int base = 0; base < B; base += 64) {
     const int b = base + lane;
     const bool live = b < B;
-    long long sl = live ? (long long)s_len[b] : 0, ql = live ? (long long)q_len[b] : 0;
+    long long sl = live ? (long long)s_len[b] : 0, ql = (live && q_len) ? (long long)q_len[b] : 0;
     sl = sl < 0 ? 0 : (sl > total_s ? total_s : sl);  // (also keeps the raw sums far from overflow)
     ql = ql < 0 ? 0 : (ql > total_q ? total_q : ql);
     const long long s_end = s_carry + rs_wave_inclusive(sl, lane), q_end = q_carry + rs_wave_inclusive(ql, lane);
@@ -225,14 +227,46 @@ __global__ __launch_bounds__(64) void rs_plan_kernel(const int* __restrict__ bbo
   }
 }
 
-__device__ __forceinline__ int rs_find_cloud(const RsPlan* __restrict__ plan, int B, long long i, bool query) {
-  int lo = 0, hi = B - 1;  // last cloud whose offset is <= i (empty clouds share an offset: the last one wins, skip them)
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    const long long off = query ? plan[mid].q_off : plan[mid].s_off;
-    if (off <= i) lo = mid; else hi = mid - 1;
+// A grid built once (v3d_radius_grid_build_f32) and searched by several query sets: the query offsets of the plan are
+// rewritten per search (one wave; the support side of the plan is left alone).
+__global__ __launch_bounds__(64) void rs_qplan_kernel(const int64_t* __restrict__ q_len, RsPlan* __restrict__ plan, int B,
+                                                      long long total_q) {
+  if (blockIdx.x != 0) return;
+  const int lane = threadIdx.x;
+  long long q_carry = 0;
+  for (int base = 0; base < B; base += 64) {
+    const int b = base + lane;
+    const bool live = b < B;
+    long long ql = live ? (long long)q_len[b] : 0;
+    ql = ql < 0 ? 0 : (ql > total_q ? total_q : ql);
+    const long long q_end = q_carry + rs_wave_inclusive(ql, lane);
+    if (live) {
+      const long long off = q_end - ql < total_q ? q_end - ql : total_q;
+      plan[b].q_off = off;
+      plan[b].q_len = (q_end < total_q ? q_end : total_q) - off;
+    }
+    q_carry = __shfl(q_end, 63, 64);
   }
-  return lo;
+}
+
+// The cloud of support `i`: the whole wave finds the cloud of ITS first support (lane l looks at cloud l * stride, then
+// inside the stride: one or two loads instead of a bisection's log2(B) dependent ones), every lane then walks on while
+// the next cloud starts at or before its own support -- supports are consecutive, so almost never.  Empty clouds share
+// an offset and the last one wins.
+__device__ __forceinline__ int rs_find_support_cloud(const RsPlan* __restrict__ plan, int B, long long i, int lane) {
+  const long long first = __shfl(i, 0, 64);
+  const int stride = (B + 63) >> 6;
+  const int i1 = lane * stride;
+  bool ok = i1 < B && plan[i1 < B ? i1 : 0].s_off <= first;
+  int c = __builtin_popcountll(__ballot(ok)) - 1;  // >= 0: cloud 0 starts at 0
+  if (stride > 1) {
+    const int i2 = c * stride + lane;
+    const bool in = lane < stride && i2 < B;
+    ok = in && plan[in ? i2 : 0].s_off <= first;
+    c = c * stride + __builtin_popcountll(__ballot(ok)) - 1;
+  }
+  while (c + 1 < B && plan[c + 1].s_off <= i) ++c;
+  return c;
 }
 
 __device__ __forceinline__ int rs_support_cell(const RsPlan& p, float x, float y, float z) {
@@ -245,8 +279,9 @@ __device__ __forceinline__ int rs_support_cell(const RsPlan& p, float x, float y
 __global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const float* __restrict__ s, const RsPlan* __restrict__ plan,
                                                               int* __restrict__ cell_count, int B, long long total_s) {
   const long long i = (long long)blockIdx.x * kRsThreads + threadIdx.x;
+  const int c = rs_find_support_cloud(plan, B, i < total_s ? i : total_s - 1, threadIdx.x & 63);  // (whole waves)
   if (i >= total_s) return;
-  const RsPlan p = plan[rs_find_cloud(plan, B, i, false)];
+  const RsPlan p = plan[c];
   atomicAdd(&cell_count[rs_support_cell(p, s[i * 3], s[i * 3 + 1], s[i * 3 + 2])], 1);
 }
 
@@ -258,8 +293,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_fill_kernel(const float* __rest
                                                              const int* __restrict__ cell_start, int* __restrict__ cursor,
                                                              float4* __restrict__ sorted, int B, long long total_s) {
   const long long i = (long long)blockIdx.x * kRsThreads + threadIdx.x;
+  const int cl = rs_find_support_cloud(plan, B, i < total_s ? i : total_s - 1, threadIdx.x & 63);  // (whole waves)
   if (i >= total_s) return;
-  const RsPlan p = plan[rs_find_cloud(plan, B, i, false)];
+  const RsPlan p = plan[cl];
   const float x = s[i * 3], y = s[i * 3 + 1], z = s[i * 3 + 2];
   const int c = rs_support_cell(p, x, y, z);
   const int slot = cell_start[c] + atomicSub(&cursor[c], 1) - 1;
@@ -374,7 +410,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_kernel(const float* __res
                                                               const int* __restrict__ cell_start,
                                                               const float4* __restrict__ sorted,
                                                               int64_t* __restrict__ out, int B, long long total_q,
-                                                              long long total_s, float radius, int limit) {
+                                                              long long total_s, float radius_sq, int limit) {
   const int lane = threadIdx.x & 63;
   const long long qi = (long long)blockIdx.x * (kRsThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (qi >= total_q) return;
@@ -397,7 +433,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_kernel(const float* __res
     const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
     const float d2 = (dx * dx + dy * dy) + dz * dz;
     const int si = __float_as_int(s.w);
-    const bool inside = valid && !(sqrtf(d2) > radius);  // radius_search.py:66 masks dist > radius
+    const bool inside = valid && d2 <= radius_sq;  // radius_search.py:66 masks dist > radius (rs_sq_threshold)
     unsigned long long m = __ballot(inside && (d2 < wd || (d2 == wd && si < wi)));
     while (m) {
       const int l = __builtin_ffsll((long long)m) - 1;
@@ -429,7 +465,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_sort_kernel(const float* 
                                                                    const int* __restrict__ cell_start,
                                                                    const float4* __restrict__ sorted,
                                                                    int64_t* __restrict__ out, int B, long long total_q,
-                                                                   long long total_s, float radius, int limit) {
+                                                                   long long total_s, float radius_sq, int limit) {
   __shared__ unsigned long long hits[kRsThreads / 64][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -457,7 +493,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_query_sort_kernel(const float* 
     const float d2 = (dx * dx + dy * dy) + dz * dz;
     const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(s.w);
     // radius_search.py:66 masks dist > radius; a NaN distance never enters the list
-    const bool take = valid && !(sqrtf(d2) > radius) && d2 < INFINITY && key < worst;
+    const bool take = valid && d2 <= radius_sq && key < worst;  // (rs_sq_threshold: finite; NaN fails)
     const unsigned long long m = __ballot(take);
     if (m == 0) continue;
     const int n = __builtin_popcountll(m);
@@ -482,7 +518,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_count_query_kernel(const float*
                                                                     const int* __restrict__ cell_start,
                                                                     const float4* __restrict__ sorted,
                                                                     int64_t* __restrict__ counts, int B, long long total_q,
-                                                                    float radius) {
+                                                                    float radius_sq) {
   const int lane = threadIdx.x & 63;
   const long long qi = (long long)blockIdx.x * (kRsThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (qi >= total_q) return;
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_count_query_kernel(const float*
     const float4 s = sorted[runs.slot(valid ? t : 0)];
     const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
     const float d2 = (dx * dx + dy * dy) + dz * dz;
-    cnt += __builtin_popcountll(__ballot(valid && (radius - sqrtf(d2) > 0.f)));  // relu(radius - d).sign()
+    cnt += __builtin_popcountll(__ballot(valid && d2 <= radius_sq));  // relu(radius - d).sign() (rs_sq_threshold, strict)
   }
   if (lane == 0) counts[qi] = (int64_t)cnt;
 }
@@ -786,20 +822,48 @@ size_t v3d_radius_search_workspace_bytes(int B, int64_t total_s) {
 }  // extern "C"
 
 namespace v3d {
+// The reference masks on the ROOT of the squared distance (`dist > radius`, radius_search.py:66; the count on
+// `radius - dist > 0`, :104).  sqrtf is correctly rounded, hence monotone: NOT(sqrtf(d2) > radius) holds exactly for the
+// d2 up to the largest float whose root is <= radius (strict: < radius) -- found here once, on the host, so that the
+// kernels compare squared distances and skip a correctly rounded root (~15 instructions) per candidate.  Returns -1 when
+// no d2 >= 0 qualifies; never +inf (an infinite d2 fails the reference's test too: it is beyond every real radius, and
+// against radius = inf the list drops it as it drops NaN).
+static float rs_sq_threshold(float radius, bool strict) {
+  auto ok = [&](float v) {
+    const float root = sqrtf(v);
+    return strict ? root < radius : root <= radius;
+  };
+  float t = radius * radius;
+  if (!(t <= FLT_MAX)) t = FLT_MAX;  // overflow (or radius = inf)
+  while (t > 0.f && !ok(t)) t = nextafterf(t, -INFINITY);
+  if (!ok(t)) return -1.f;
+  while (t < FLT_MAX && ok(nextafterf(t, INFINITY))) t = nextafterf(t, INFINITY);
+  return t;
+}
+
 // neighbor_limit < 0: count mode (`out` = counts (total_q,)), else search mode (`out` = neighbor_indices);
 // knn_distances != nullptr: kNN mode (neighbor_limit = k <= 64, radius unused, cells sized by density)
+// phase: the whole call, or one half of it around a caller-held grid (`cell_radius` = the radius the grid was built for:
+// its cells serve every search radius up to it)
+enum RsPhase { kRsWhole = 0, kRsBuildOnly = 1, kRsQueryOnly = 2 };
 static int rs_run(const char* what, const float* q_points, const float* s_points, const int64_t* q_lengths,
                   const int64_t* s_lengths, int64_t* neighbor_indices, int B, int64_t total_q, int64_t total_s,
                   float radius, int neighbor_limit, void* workspace, size_t workspace_bytes, int device, void* stream_,
-                  float* knn_distances = nullptr) {
+                  float* knn_distances = nullptr, RsPhase phase = kRsWhole, float cell_radius = 0.f) {
   const bool count_mode = neighbor_limit < 0;
   const float per_cell = knn_distances ? kp_supports_per_cell(neighbor_limit) : 0.f;
+  const bool build = phase != kRsQueryOnly, query = phase != kRsBuildOnly;
   V3D_REQUIRE(B >= 0 && total_q >= 0 && total_s >= 0, what, "negative dimension");
-  if (total_q == 0 || neighbor_limit == 0) return 0;
+  if (query && (total_q == 0 || neighbor_limit == 0)) return 0;
   V3D_REQUIRE(B > 0, what, "points without clouds");
-  V3D_REQUIRE(q_points && q_lengths && s_lengths && neighbor_indices && (total_s == 0 || s_points), what,
-              "null pointer");
+  V3D_REQUIRE((!query || (q_points && q_lengths && neighbor_indices)) &&
+                  (!build || (s_lengths && (total_s == 0 || s_points))),
+              what, "null pointer");
   V3D_REQUIRE(radius >= 0.f, what, "negative radius");  // NaN fails too
+  if (phase != kRsWhole) {
+    V3D_REQUIRE(workspace != nullptr, what, "a grid is held by the caller: NULL workspace");
+    V3D_REQUIRE(cell_radius >= 0.f && radius <= cell_radius, what, "search radius beyond the radius the grid was built for");
+  }
   if (neighbor_limit > V3D_RADIUS_MAX_LIMIT) {
     set_last_error("%s: neighbor_limit=%d exceeds %d", what, neighbor_limit, V3D_RADIUS_MAX_LIMIT);
     return V3D_ERR_K_TOO_LARGE;
@@ -826,7 +890,11 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
   RsWorkspace ws = rs_carve(base, B, total_s);
   int rc = 0;
   do {
-    hipError_t e = hipMemsetAsync(ws.cell_count, 0, sizeof(int) * (size_t)rs_cell_capacity(B, total_s), stream);
+    hipError_t e = hipSuccess;
+    if (!build) {
+      hipLaunchKernelGGL(rs_qplan_kernel, dim3(1), dim3(64), 0, stream, q_lengths, ws.plan, B, (long long)total_q);
+    } else {
+    e = hipMemsetAsync(ws.cell_count, 0, sizeof(int) * (size_t)rs_cell_capacity(B, total_s), stream);
     if (e != hipSuccess) {
       set_last_error("%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
       rc = (int)e;
@@ -836,8 +904,9 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
                        B);
     hipLaunchKernelGGL(rs_bbox_kernel, dim3(B, kRsBboxSplit), dim3(kRsThreads), 0, stream, s_points, s_lengths, ws.bbox,
                        (long long)total_s);
-    hipLaunchKernelGGL(rs_plan_kernel, dim3(1), dim3(64), 0, stream, ws.bbox, q_lengths, s_lengths, ws.plan, B, radius,
-                       (long long)total_s, (long long)total_q, per_cell);
+    hipLaunchKernelGGL(rs_plan_kernel, dim3(1), dim3(64), 0, stream, ws.bbox, query ? q_lengths : nullptr, s_lengths,
+                       ws.plan, B, phase == kRsWhole ? radius : cell_radius, (long long)total_s, (long long)total_q,
+                       per_cell);
     const size_t cap = (size_t)rs_cell_capacity(B, total_s);
     if (total_s > 0) {
       const unsigned sb = (unsigned)ceil_div(total_s, kRsThreads);
@@ -857,6 +926,11 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
       hipLaunchKernelGGL(rs_fill_kernel, dim3(sb), dim3(kRsThreads), 0, stream, s_points, ws.plan, ws.cell_start,
                          ws.cell_count, ws.sorted, B, (long long)total_s);
     }
+    }  // build
+    if (!query) {
+      rc = launch_status(what);
+      break;
+    }
     const unsigned qb = (unsigned)ceil_div(total_q, kRsThreads / 64);
     if (knn_distances && neighbor_limit <= 3)
       hipLaunchKernelGGL(kp_query_kernel<2>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
@@ -866,23 +940,23 @@ static int rs_run(const char* what, const float* q_points, const float* s_points
                          ws.sorted, knn_distances, neighbor_indices, B, (long long)total_q, neighbor_limit);
     else if (count_mode)
       hipLaunchKernelGGL(rs_count_query_kernel, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
-                         ws.sorted, neighbor_indices, B, (long long)total_q, radius);
+                         ws.sorted, neighbor_indices, B, (long long)total_q, rs_sq_threshold(radius, true));
     else if (neighbor_limit <= 64)
       hipLaunchKernelGGL(rs_query_sort_kernel, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
-                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
-                         neighbor_limit);
+                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s,
+                         rs_sq_threshold(radius, false), neighbor_limit);
     else if (neighbor_limit <= 128)
       hipLaunchKernelGGL(rs_query_kernel<2>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
-                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
-                         neighbor_limit);
+                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s,
+                         rs_sq_threshold(radius, false), neighbor_limit);
     else if (neighbor_limit <= 256)
       hipLaunchKernelGGL(rs_query_kernel<4>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
-                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
-                         neighbor_limit);
+                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s,
+                         rs_sq_threshold(radius, false), neighbor_limit);
     else
       hipLaunchKernelGGL(rs_query_kernel<8>, dim3(qb), dim3(kRsThreads), 0, stream, q_points, ws.plan, ws.cell_start,
-                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s, radius,
-                         neighbor_limit);
+                         ws.sorted, neighbor_indices, B, (long long)total_q, (long long)total_s,
+                         rs_sq_threshold(radius, false), neighbor_limit);
     rc = launch_status(what);
   } while (0);
   if (own) {
@@ -913,6 +987,20 @@ int v3d_radius_search_pack_f32(const float* q_points, const float* s_points, con
   if (neighbor_limit < 0) return v3d::invalid("radius_search_pack_mode", "negative dimension");
   return v3d::rs_run("radius_search_pack_mode", q_points, s_points, q_lengths, s_lengths, neighbor_indices, B, total_q,
                      total_s, radius, neighbor_limit, workspace, workspace_bytes, device, stream);
+}
+
+int v3d_radius_grid_build_f32(const float* s_points, const int64_t* s_lengths, int B, int64_t total_s, float cell_radius,
+                              void* grid, size_t grid_bytes, int device, void* stream) {
+  return v3d::rs_run("radius_grid_build", nullptr, s_points, nullptr, s_lengths, nullptr, B, 0, total_s, cell_radius, 1,
+                     grid, grid_bytes, device, stream, nullptr, v3d::kRsBuildOnly, cell_radius);
+}
+
+int v3d_radius_search_grid_f32(const float* q_points, const int64_t* q_lengths, int64_t* neighbor_indices, int B,
+                               int64_t total_q, int64_t total_s, float cell_radius, float radius, int neighbor_limit,
+                               void* grid, size_t grid_bytes, int device, void* stream) {
+  if (neighbor_limit < 0) return v3d::invalid("radius_search_grid", "negative dimension");
+  return v3d::rs_run("radius_search_grid", q_points, nullptr, q_lengths, nullptr, neighbor_indices, B, total_q, total_s,
+                     radius, neighbor_limit, grid, grid_bytes, device, stream, nullptr, v3d::kRsQueryOnly, cell_radius);
 }
 
 int v3d_radius_count_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths,

@@ -50,22 +50,6 @@ __device__ __forceinline__ wkey_t wave_insert_asc(wkey_t kept, wkey_t key, int l
   const wkey_t shifted = ((wkey_t)hi << 32) | lo;
   return lane == pos ? key : (lane > pos ? shifted : kept);
 }
-// Merge the first n (wave-uniform, 1..64) keys of a per-wave LDS buffer into `kept` (ascending, 64 smallest survive).
-constexpr int kWaveSerialKeys = 12;  // up to here one shifted insertion per key beats the network
-// `kept_empty` (wave-uniform): every entry of `kept` is kWaveKeyMax, so sorting the buffer ascending is the whole merge.
-__device__ __forceinline__ wkey_t wave_merge_buffer(wkey_t kept, const wkey_t* buf, int n, int lane,
-                                                    bool kept_empty = false) {
-  __builtin_amdgcn_wave_barrier();
-  wkey_t h = lane < n ? buf[lane] : kWaveKeyMax;
-  __builtin_amdgcn_wave_barrier();
-  if (n <= kWaveSerialKeys) {
-    for (int e = 0; e < n; ++e) kept = wave_insert_asc(kept, wave_lane64(h, e), lane);
-  } else {
-    h = wave_sort(h, lane, !kept_empty);
-    kept = kept_empty ? h : wave_merge_asc(h < kept ? h : kept, lane);
-  }
-  return kept;
-}
 // The first n (wave-uniform, 0..64) DISTINCT keys of a per-wave LDS buffer -> ascending across the lanes, kWaveKeyMax behind
 // them.  Every lane counts the keys below its own (n broadcast reads, no cross-lane round trips) and the keys change
 // places through the buffer: cheaper than the 21-step network while n is a few dozen.  The buffer is left sorted.
@@ -81,6 +65,25 @@ __device__ __forceinline__ wkey_t wave_rank_sort(wkey_t* buf, int n, int lane) {
   const wkey_t out = lane < n ? buf[lane] : kWaveKeyMax;
   __builtin_amdgcn_wave_barrier();
   return out;
+}
+// Merge the first n (wave-uniform, 1..64) keys of a per-wave LDS buffer into `kept` (ascending, 64 smallest survive).
+constexpr int kWaveSerialKeys = 12;  // up to here one shifted insertion per key beats the network
+// `kept_empty` (wave-uniform): every entry of `kept` is kWaveKeyMax, so sorting the buffer ascending is the whole merge
+// (the keys of one buffer are distinct: they carry the support index).
+constexpr int kWaveRankKeys = 48;    // up to here (and nothing kept yet) counting ranks beats the 21-step network
+__device__ __forceinline__ wkey_t wave_merge_buffer(wkey_t kept, wkey_t* buf, int n, int lane,
+                                                    bool kept_empty = false) {
+  if (kept_empty && n > kWaveSerialKeys && n <= kWaveRankKeys) return wave_rank_sort(buf, n, lane);
+  __builtin_amdgcn_wave_barrier();
+  wkey_t h = lane < n ? buf[lane] : kWaveKeyMax;
+  __builtin_amdgcn_wave_barrier();
+  if (n <= kWaveSerialKeys) {
+    for (int e = 0; e < n; ++e) kept = wave_insert_asc(kept, wave_lane64(h, e), lane);
+  } else {
+    h = wave_sort(h, lane, !kept_empty);
+    kept = kept_empty ? h : wave_merge_asc(h < kept ? h : kept, lane);
+  }
+  return kept;
 }
 __device__ __forceinline__ int wave_prefix_count(unsigned long long m) {  // set bits of m below this lane
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));

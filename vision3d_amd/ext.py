@@ -467,6 +467,50 @@ def radius_search_pack(q_points, s_points, q_lengths, s_lengths, neighbor_indice
     _lib.check(rc, "radius_search_pack_mode")
 
 
+class RadiusGrid:
+    """The cell list of one support set (``radius_grid_build``): serves ``radius_search_grid`` at every radius up to
+    ``cell_radius``.  Searches on one grid must be stream-ordered (each rewrites the query offsets kept in it)."""
+
+    __slots__ = ("workspace", "num_clouds", "num_supports", "cell_radius", "s_points", "s_lengths")
+
+    def __init__(self, workspace, num_clouds, num_supports, cell_radius, s_points, s_lengths):
+        self.workspace, self.num_clouds, self.num_supports = workspace, num_clouds, num_supports
+        self.cell_radius, self.s_points, self.s_lengths = cell_radius, s_points, s_lengths  # (inputs kept alive)
+
+
+def radius_grid_build(s_points, s_lengths, cell_radius):
+    """s_points (N,3) fp32, s_lengths (B,) int64 on the same device -> RadiusGrid for radii <= cell_radius."""
+    _check_cuda_contiguous(s_points, "s_points")
+    _check_cuda_contiguous(s_lengths, "s_lengths")
+    _check_float(s_points, "s_points")
+    _check_long(s_lengths, "s_lengths")
+    B, N = s_lengths.shape[0], s_points.shape[0]
+    dev, stream = _where(s_points)
+    ws = _workspace(_lib.lib().v3d_radius_search_workspace_bytes(B, N), s_points)
+    _lib.check(_lib.lib().v3d_radius_grid_build_f32(s_points.data_ptr(), s_lengths.data_ptr(), B, N, float(cell_radius),
+                                                   ws.data_ptr(), ws.numel(), dev, stream), "radius_grid_build")
+    return RadiusGrid(ws, B, N, float(cell_radius), s_points, s_lengths)
+
+
+def radius_search_grid(q_points, q_lengths, grid, neighbor_indices, radius, neighbor_limit):
+    """``radius_search_pack`` against the supports of ``grid`` (identical result); radius <= grid.cell_radius."""
+    for t, name in ((q_points, "q_points"), (q_lengths, "q_lengths"), (neighbor_indices, "neighbor_indices")):
+        _check_cuda_contiguous(t, name)
+    _check_float(q_points, "q_points")
+    _check_long(q_lengths, "q_lengths")
+    _check_long(neighbor_indices, "neighbor_indices")
+    if q_lengths.shape[0] != grid.num_clouds:
+        raise RuntimeError("q_lengths and the grid must have the same number of clouds")
+    M = q_points.shape[0]
+    if neighbor_indices.numel() != M * int(neighbor_limit):
+        raise RuntimeError("neighbor_indices must hold neighbor_limit entries per query")
+    dev, stream = _where(q_points)
+    _lib.check(_lib.lib().v3d_radius_search_grid_f32(
+        q_points.data_ptr(), q_lengths.data_ptr(), neighbor_indices.data_ptr(), grid.num_clouds, M, grid.num_supports,
+        grid.cell_radius, float(radius), int(neighbor_limit), grid.workspace.data_ptr(), grid.workspace.numel(), dev,
+        stream), "radius_search_grid")
+
+
 def knn_lex(q_points, s_points, knn_distances, knn_indices, num_neighbors):
     """q_points (B,M,3), s_points (B,N,3) fp32 -> knn_distances (B,M,k) ascending, knn_indices (B,M,k) int64; equal
     distances lower index first (the order pykeops' Kmin_argKmin yields; ``knn_points`` keeps the CUDA heap's)."""
