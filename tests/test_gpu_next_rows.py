@@ -1102,6 +1102,28 @@ def test_next_row_entry_points_take_caller_owned_workspaces():
                                                          osc2.data_ptr(), num.data_ptr(), cap, p, n, dev, stream),
              lambda: [orow2, ocol2, osc2, num])
     assert lib.v3d_threshold_select_workspace_bytes(100, 100) == 0  # one-launch size: no scratch at all
+    # pack-mode radius search and kNN: pair-by-pair route (small clouds) and cell-list route (clouds of >= 2048 supports)
+    for lens_s, lens_q in (((300, 200), (100, 150)), ((3000, 2500), (400, 300))):
+        ns, nq = sum(lens_s), sum(lens_q)
+        sp = torch.rand((ns, 3), generator=g).to(DEV)
+        qp = torch.rand((nq, 3), generator=g).to(DEV)
+        sl = torch.tensor(lens_s, device=DEV)
+        ql = torch.tensor(lens_q, device=DEV)
+        kd = torch.zeros((nq, 5), device=DEV)
+        ki = torch.zeros((nq, 5), dtype=torch.long, device=DEV)
+        both(lib.v3d_knn_pack_workspace_bytes(2, ns, 5),
+             lambda p, n: lib.v3d_knn_pack_f32(qp.data_ptr(), sp.data_ptr(), ql.data_ptr(), sl.data_ptr(), kd.data_ptr(),
+                                               ki.data_ptr(), 2, nq, ns, 5, p, n, dev, stream),
+             lambda: [kd, ki])
+        tab = torch.zeros((nq, 12), dtype=torch.long, device=DEV)
+        both(lib.v3d_radius_search_workspace_bytes(2, ns),
+             lambda p, n: lib.v3d_radius_search_pack_f32(qp.data_ptr(), sp.data_ptr(), ql.data_ptr(), sl.data_ptr(),
+                                                         tab.data_ptr(), 2, nq, ns, 0.1, 12, p, n, dev, stream),
+             lambda: [tab])
+    assert lib.v3d_knn_pack_workspace_bytes(2, 5500, 5) > lib.v3d_knn_pack_workspace_bytes(2, 500, 5)
+    # a caller-held grid is never optional
+    rc = lib.v3d_radius_grid_build_f32(sp.data_ptr(), sl.data_ptr(), 2, ns, 0.1, None, 0, dev, stream)
+    assert rc != 0 and b"NULL workspace" in lib.v3d_last_error_string()
 
 
 def test_radius_grid_built_once_serves_several_query_sets_and_radii(ext, oracle_mod):
