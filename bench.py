@@ -434,6 +434,25 @@ def per_config_single(torch, device):
     out["c1_pointnet2_ssg"] = {"workload": "B16 N1024 FPS->512, ball_query r0.2 k32, group_gather C64 (+xyz)",
                                "ms_per_step": ms, "queries_per_sec": b1 * m1 / (ms * 1e-3),
                                "fps_points_per_sec": b1 * n1 / (ms_fps * 1e-3), "fps_ms": ms_fps}
+    # ---- C2 queries one by one: the MSG shapes (B=32, N=4096, M=1024) through ball_query / knn_points / three_nn
+    b2, n2, m2 = 32, 4096, 1024
+    p2 = torch.rand((b2, n2, 3), generator=g).to(device)
+    q2 = p2[:, :m2].contiguous()
+    c2q = {"workload": "B32 N4096 M1024 uniform cloud: one launch per entry"}
+    for k2, r2 in ((16, 0.1), (32, 0.2)):
+        bi2 = torch.zeros((b2, m2, k2), dtype=torch.long, device=device)
+        kd2 = torch.empty((b2, m2, k2), device=device)
+        ms_b = _loop_ms(torch, lambda: ext.ball_query(q2, p2, bi2, r2, k2), 30)
+        ms_k = _loop_ms(torch, lambda: ext.knn_points(q2, p2, kd2, bi2, k2), 30)
+        ms_l = _loop_ms(torch, lambda: ext.knn_lex(q2, p2, kd2, bi2, k2), 30)
+        c2q[f"k{k2}"] = {"ball_query_ms": ms_b, "knn_points_ms": ms_k, "knn_points_queries_per_sec": b2 * m2 / (ms_k * 1e-3),
+                         "knn_index_order_ms": ms_l}
+    td2 = torch.empty((b2, n2, 3), device=device)
+    ti2 = torch.empty((b2, n2, 3), dtype=torch.long, device=device)
+    ms_t = _loop_ms(torch, lambda: ext.three_nn(p2, q2, td2, ti2), 30)
+    c2q["three_nn_4096_from_1024"] = {"ms": ms_t, "queries_per_sec": b2 * n2 / (ms_t * 1e-3)}
+    out["c2_queries"] = c2q
+    del p2, q2, td2, ti2
     # ---- C3: DGCNN feature-space kNN, B=32, N=1024, C=64, k=20 (self included)
     b3, n3, c3, k3 = 32, 1024, 64, 20
     x = torch.randn((b3, n3, c3), generator=g).to(device)
@@ -456,7 +475,16 @@ def per_config_single(torch, device):
     out["c4_kpconv_pyramid_stage"] = {"workload": "16 clouds x 30000 pts, radius 0.0625 limit 38, voxel 0.025",
                                       "radius_search_ms": ms_r, "radius_queries_per_sec": nc * n4 / (ms_r * 1e-3),
                                       "grid_subsample_ms": ms_g, "grid_points_per_sec": nc * n4 / (ms_g * 1e-3)}
-    del pts, table, o
+    # decoder side of the same stage: every point's nearest / three nearest points of the next (coarser) stage, pack mode
+    sub = (torch.rand((nc * n4 // 4, 3), generator=g) * torch.tensor([3.0, 3.0, 2.5])).to(device)
+    sub_lengths = torch.full((nc,), n4 // 4, dtype=torch.long, device=device)
+    for kk in (1, 3):
+        kd4 = torch.empty((nc * n4, kk), device=device)
+        ki4 = torch.empty((nc * n4, kk), dtype=torch.long, device=device)
+        ms_k = _loop_ms(torch, lambda: ext.knn_pack(pts, sub, lengths, sub_lengths, kd4, ki4, kk), 30)
+        out["c4_kpconv_pyramid_stage"][f"knn_pack_k{kk}_ms"] = ms_k
+        out["c4_kpconv_pyramid_stage"][f"knn_pack_k{kk}_queries_per_sec"] = nc * n4 / (ms_k * 1e-3)
+    del pts, table, o, sub
     job = C4Pyramid(torch, None, device, 1, 0)
     job.count_queries()
     ms_p = _loop_ms(torch, job.step, 5, warm=2)
