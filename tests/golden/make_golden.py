@@ -570,6 +570,21 @@ def make_pack_glue_fixtures():
         assert torch.equal(fast, naive)
         out.update(rs_q=q, rs_s=s, rs_q_lengths=ql, rs_s_lengths=sl_, rs_radius=np.float64(radius),
                    rs_limit=np.int64(limit), rs_table=fast.numpy(), rs_seed=np.int64(seed))
+        # ---- ops/knn.py:110-145 `knn_pack_mode` (and :30-107 `knn` on 3-D points) by the reference's own file: its
+        # module-level `from pykeops.torch import LazyTensor` gets the raising name above, its `keops_knn` (:10-27, the
+        # only user of LazyTensor) is replaced by the same stand-in.  Pins the glue -- padding to the longest cloud with
+        # 1e10, indices inside the cloud, ascending distances, un-padding -- on tie-free clouds, not pykeops.
+        del sys.modules["v3dref_ops.knn"]
+        real_knn = importlib.import_module("v3dref_ops.knn")
+        real_knn.keops_knn = keops_knn
+        kq, ks = torch.from_numpy(q), torch.from_numpy(s)
+        for k in (1, 3, 16):
+            kd, ki = real_knn.knn_pack_mode(kq, ks, torch.from_numpy(ql), torch.from_numpy(sl_), k, return_distance=True)
+            out[f"kp_k{k}_dist"], out[f"kp_k{k}_idx"] = kd.numpy(), ki.numpy()
+        bq, bs = kq[:120].reshape(2, 60, 3), ks[:400].reshape(2, 200, 3)
+        bd, bi = real_knn.knn(bq, bs, 5, return_distance=True)
+        bd2, bi2 = real_knn.knn(bq, bs, 4, dilation=2, remove_nearest=True, return_distance=True)
+        out.update(kb_dist=bd.numpy(), kb_idx=bi.numpy(), kb_dil_dist=bd2.numpy(), kb_dil_idx=bi2.numpy())
         np.savez_compressed(os.path.join(HERE, "ref_pack_glue.npz"), **out)
     finally:
         torch.Tensor.cuda = orig_cuda

@@ -1077,6 +1077,28 @@ def test_radius_search_pack_vs_reference_glue_fixture(ext, golden):
     assert np.array_equal(N_(pk), g["cv_packed"]) and np.array_equal(N_(pl), g["cv_wide_relengths"])
 
 
+def test_knn_pack_and_knn_vs_reference_glue_fixture(ext, golden):
+    """ops.knn_pack_mode (native and padded route) and ops.knn on 3-D points (plain, dilated + remove_nearest) against the
+    reference's ops/knn.py:110-145 / :30-107 run around a stand-in kNN (tests/golden/ref_pack_glue.npz; tie-free clouds)."""
+    from vision3d_amd import ops
+    from vision3d_amd.ops.knn import padded_knn_pack_mode
+
+    g = golden("ref_pack_glue.npz")
+    q, s, ql, sl = T(g["rs_q"]), T(g["rs_s"]), T(g["rs_q_lengths"]), T(g["rs_s_lengths"])
+    for k in (1, 3, 16):
+        for fn in (ops.knn_pack_mode, padded_knn_pack_mode):
+            d, i = fn(q, s, ql, sl, k, return_distance=True)
+            assert np.array_equal(N_(i), g[f"kp_k{k}_idx"]), (k, fn.__name__)
+            np.testing.assert_allclose(N_(d), g[f"kp_k{k}_dist"], rtol=0, atol=2e-6)
+    bq, bs = q[:120].reshape(2, 60, 3), s[:400].reshape(2, 200, 3)
+    d, i = ops.knn(bq, bs, 5, return_distance=True)
+    assert np.array_equal(N_(i), g["kb_idx"])
+    np.testing.assert_allclose(N_(d), g["kb_dist"], rtol=0, atol=2e-6)
+    d, i = ops.knn(bq, bs, 4, dilation=2, remove_nearest=True, return_distance=True)
+    assert np.array_equal(N_(i), g["kb_dil_idx"])
+    np.testing.assert_allclose(N_(d), g["kb_dil_dist"], rtol=0, atol=2e-6)
+
+
 def test_c4_full_size_radius_search_count_and_grid_subsample(ext, oracle_mod):
     """BASELINE config 4 at full size: 16 clouds x 30,000 points in a 3 x 3 x 2.5 m box, radius 0.0625 with
     limit 38 and a denser radius 0.2 (more hits than the limit), voxel 0.025.  Radius search / count: oracle comparison on
