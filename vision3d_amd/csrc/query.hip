@@ -12,12 +12,14 @@
 //                  so far live sorted, one entry per lane, and a chunk is filtered by one compare + ballot against
 //                  the (k+1)-th best; survivors are inserted with a whole-wave DPP shift.  If the final k+1
 //                  distances are all different the reference's heap can only yield this list; otherwise (exact
-//                  ties) that query is replayed through the reference's max-heap (LDS, wave-uniform sifts), so
-//                  ties come out in exactly the reference's order.
+//                  ties) that query is replayed through the reference's max-heap (one slot per lane, sifted by the
+//                  whole wave), so ties come out in exactly the reference's order.  Clouds of 2048..4096 supports
+//                  (fp32, k <= 63) are searched on a cell list each workgroup builds in LDS
+//                  (knn_points_grid_kernel) -- same k+1 keys, same replay.  v3d_knn_lex_f32 (what ops.knn runs for
+//                  3-D points) and v3d_knn_pack_f32 leave equal distances lower index first (pykeops' order): the
+//                  list itself, no replay; pack mode sends clouds of >= 2048 supports to radius.hip's cell list.
 // Squared distances use the reference's expression order with one rounding per operation (the library is
 // compiled with -ffp-contract=off).
-#include <stdlib.h>
-
 #include <cmath>
 #include <mutex>
 #include <type_traits>

@@ -1,4 +1,4 @@
-// radius.hip -- radius neighbours and radius counts in PACK mode (variable-length clouds concatenated: points (total,3) + lengths (B,)).
+// radius.hip -- radius neighbours, radius counts and kNN in PACK mode (variable-length clouds concatenated: points (total,3) + lengths (B,)).
 // Replaces `radius_search_pack_mode` of the reference (vision3d/ops/radius_search.py:44-71): pack -> padded batch ->
 // pykeops brute-force kNN(limit) -> mask (dist > radius) -> batch -> pack, with Python loops and .item() syncs in the
 // conversions (ops/conversion.py:7-12,69-81).  Same result definition: per query, the supports of its own cloud with
@@ -17,7 +17,14 @@
 //                          and merged into the kept list by a bitonic network; limit <= 512: lane-distributed sorted
 //                          list with a whole-wave DPP shift per hit.  rs_count_query: popcount of the hits.
 //                          The result does not depend on the order candidates arrive in.
-// Distances use the reference expression order (dx*dx + dy*dy) + dz*dz with one rounding per operation.
+//   4. kp_query_kernel   : pack-mode kNN (ops/knn.py:110-145) on the same cell list, cells sized by the cloud's density:
+//                          a first box of 3x3x3 (k <= 3: 2x2x2) cells, then one more layer of cells at a time until the
+//                          k-th distance lies inside the explored box (v3d_knn_pack_f32 in query.hip sends clouds of
+//                          >= 2048 supports here).
+// Steps 1-2 can be kept by the caller and searched several times (v3d_radius_grid_build_f32 / v3d_radius_search_grid_f32:
+// the pyramid builder searches the points of a stage three times at one radius).
+// Distances use the reference expression order (dx*dx + dy*dy) + dz*dz with one rounding per operation; the radius
+// test on sqrt(d2) is made on d2 against a threshold found on the host (rs_sq_threshold).
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
