@@ -176,8 +176,10 @@ __global__ __launch_bounds__(kGsThreads) void gs_feats_kernel(const float* __res
 }
 
 // Per-cloud counts without atomics: the first record of a cloud is a voxel head, so the exclusive head count there is
-// the number of voxels of all earlier clouds (:92-94 computes the same with bincount).
-__global__ void gs_lengths_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ flags,
+// the number of voxels of all earlier clouds (:92-94 computes the same with bincount).  Where a cloud's records start in
+// the sorted order needs no search: the keys carry the cloud number in their top bits and gs_keys_kernel numbered record
+// i with the last cloud whose offset is <= i, so the records of clouds < c are the first min(offsets[c], total).
+__global__ void gs_lengths_kernel(const long long* __restrict__ offsets, const int* __restrict__ flags,
                                   const int* __restrict__ slots, int64_t* __restrict__ out_len, int B,
                                   long long total) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,12 +187,8 @@ __global__ void gs_lengths_kernel(const unsigned long long* __restrict__ keys, c
   long long bound[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {  // first record whose cloud is >= b + e
-    const unsigned long long want = (unsigned long long)(b + e);
-    long long lo = 0, hi = total;
-    while (lo < hi) {
-      const long long mid = (lo + hi) >> 1;
-      if ((keys[mid] >> (3 * kGsCoordBits)) < want) lo = mid + 1; else hi = mid;
-    }
+    long long lo = b + e >= B ? total : offsets[b + e];
+    lo = lo < 0 ? 0 : (lo > total ? total : lo);
     bound[e] = lo < total ? (long long)slots[lo] : (long long)slots[total - 1] + flags[total - 1];
   }
   out_len[b] = bound[1] - bound[0];
@@ -311,7 +309,7 @@ static int grid_reduce(const char* what, const float* points, const int64_t* len
     if (C > 0)
       hipLaunchKernelGGL(gs_feats_kernel, dim3((unsigned)ceil_div(total * C, kGsThreads)), dim3(kGsThreads), 0, stream,
                          feats, v1, flags, head_pos, num_sampled, C, (long long)total, out_feats);
-    hipLaunchKernelGGL(gs_lengths_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, stream, k1, flags, slots,
+    hipLaunchKernelGGL(gs_lengths_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, stream, offsets, flags, slots,
                        sampled_lengths, B, (long long)total);
     rc = launch_status(what);
   } while (0);
