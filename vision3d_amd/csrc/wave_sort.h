@@ -70,10 +70,11 @@ __device__ __forceinline__ wkey_t wave_rank_sort(wkey_t* buf, int n, int lane) {
 constexpr int kWaveSerialKeys = 12;  // up to here one shifted insertion per key beats the network
 // `kept_empty` (wave-uniform): every entry of `kept` is kWaveKeyMax, so sorting the buffer ascending is the whole merge
 // (the keys of one buffer are distinct: they carry the support index).
-constexpr int kWaveRankKeys = 48;    // up to here (and nothing kept yet) counting ranks beats the 21-step network
+constexpr int kWaveRankKeys = 48;    // up to here (and nothing kept yet) counting ranks beats the 21-step network ...
+constexpr int kWaveRankMinKeys = 2;  // ... and from here on the shifted insertions (3 n + ~20 instructions against ~25 n)
 __device__ __forceinline__ wkey_t wave_merge_buffer(wkey_t kept, wkey_t* buf, int n, int lane,
                                                     bool kept_empty = false) {
-  if (kept_empty && n > kWaveSerialKeys && n <= kWaveRankKeys) return wave_rank_sort(buf, n, lane);
+  if (kept_empty && n >= kWaveRankMinKeys && n <= kWaveRankKeys) return wave_rank_sort(buf, n, lane);
   __builtin_amdgcn_wave_barrier();
   wkey_t h = lane < n ? buf[lane] : kWaveKeyMax;
   __builtin_amdgcn_wave_barrier();
