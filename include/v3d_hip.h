@@ -237,9 +237,14 @@ int v3d_radius_search_grid_f32(const float* q_points, const int64_t* q_lengths, 
  * scanning the supports in index order) and of v3d_radius_search_pack_f32; NOT the heap order of v3d_knn_points_f32.
  * k <= V3D_KNN_MAX_K; a cloud with fewer than k supports (the reference asserts against it, :137) leaves (1e5, 0) in the
  * unfilled slots like v3d_knn_points_f32; lengths that overrun the totals are cut.  Clouds averaging >= 2048 supports
- * (k <= 64, B <= 4096) are searched on the radius search's cell list, smaller ones pair by pair.  No host
+ * (k <= 64, B <= 4096, enough queries to pay for the build) are searched on the radius search's cell list, the rest pair
+ * by pair.  No host
  * synchronisation.  Scratch: v3d_knn_pack_workspace_bytes(B, total_s, k) bytes or NULL (stream-ordered allocation). */
 size_t v3d_knn_pack_workspace_bytes(int B, int64_t total_s, int k);
+/* 1 if a call with these sizes is searched on the cell list, 0 if pair by pair (a handful of queries against large clouds
+ * stay pair by pair: the cell list costs ~50 us of launches + a counting sort of the supports).  Informational -- the
+ * result is the same either way; tests use it to know which kernels they exercise.  No counterpart in the reference. */
+int v3d_knn_pack_uses_cell_list(int B, int64_t total_q, int64_t total_s, int k);
 int v3d_knn_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
                      float* distances, int64_t* indices, int B, int64_t total_q, int64_t total_s, int k,
                      void* workspace, size_t workspace_bytes, int device, void* stream);

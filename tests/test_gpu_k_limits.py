@@ -224,6 +224,9 @@ def test_knn_pack_native_vs_per_cloud_oracle(ext, oracle_mod, case, k):
         qc = [rng.random((n, 3), dtype=np.float32) for n in case["q"]]
     q, s = np.concatenate(qc), np.concatenate(sc)
     ql, sl = np.asarray(case["q"], np.int64), np.asarray(case["s"], np.int64)
+    from vision3d_amd import _lib
+
+    assert _lib.lib().v3d_knn_pack_uses_cell_list(len(sl), q.shape[0], s.shape[0], k) == 0
     wd, wi = _knn_pack_oracle(oracle_mod, q, s, ql, sl, k)
     d = torch.full((q.shape[0], k), -1.0, device=DEV)
     idx = torch.full((q.shape[0], k), -7, dtype=torch.long, device=DEV)
@@ -293,21 +296,36 @@ def test_knn_pack_cell_list_vs_oracle(ext, oracle_mod, name):
     """Clouds of a few thousand supports: v3d_knn_pack_f32 searches them on the radius search's cell list.  The search
     is exact -- identical indices and distances to the pair-by-pair oracle, equal distances lower index first -- on
     uniform, surface-like, clustered, tie-heavy, degenerate and non-finite clouds."""
+    from vision3d_amd import _lib
+
     qc, sc = _cell_list_pack_case(name, np.random.default_rng(91))
     q, s = np.concatenate(qc), np.concatenate(sc)
     ql = np.asarray([len(c) for c in qc], np.int64)
     sl = np.asarray([len(c) for c in sc], np.int64)
-    assert s.shape[0] // len(sl) >= 2048
+    # The cell list is only taken when there are enough queries to pay for its build: every cloud's queries are
+    # repeated `rep` times (the oracle answers them once; every copy must get that answer).
+    rep = -(-200000 // q.shape[0])
+    q_rep = np.concatenate([np.tile(c, (rep, 1)) for c in qc])
+    ql_rep = ql * rep
     oracle_mod.set_threads(oracle_mod.max_threads())
     try:
         for k in (1, 3, 16, 38, 64):
+            assert _lib.lib().v3d_knn_pack_uses_cell_list(len(sl), q_rep.shape[0], s.shape[0], k) == 1
             with np.errstate(all="ignore"):
                 wd, wi = oracle_mod.knn_pack(q, s, ql, sl, k)
-            d = torch.full((q.shape[0], k), -1.0, device=DEV)
-            idx = torch.full((q.shape[0], k), -7, dtype=torch.long, device=DEV)
-            ext.knn_pack(T(q), T(s), T(ql), T(sl), d, idx, k)
-            assert np.array_equal(N_(idx), wi), (name, k)
-            assert np.array_equal(N_(d), wd, equal_nan=True), (name, k)
+            d = torch.full((q_rep.shape[0], k), -1.0, device=DEV)
+            idx = torch.full((q_rep.shape[0], k), -7, dtype=torch.long, device=DEV)
+            ext.knn_pack(T(q_rep), T(s), T(ql_rep), T(sl), d, idx, k)
+            gd, gi = N_(d), N_(idx)
+            qo = ro = 0
+            for n in ql:
+                n = int(n)
+                for r in range(rep):
+                    rows = slice(ro + r * n, ro + (r + 1) * n)
+                    assert np.array_equal(gi[rows], wi[qo:qo + n]), (name, k, r)
+                    assert np.array_equal(gd[rows], wd[qo:qo + n], equal_nan=True), (name, k, r)
+                qo += n
+                ro += n * rep
     finally:
         oracle_mod.set_threads(1)
 
@@ -324,6 +342,9 @@ def test_knn_pack_cell_list_equals_pairwise_kernels_at_pyramid_size(ext):
     sl = torch.full((nc,), ns, dtype=torch.long, device=DEV)
     d = torch.empty((nc * nq, k), device=DEV)
     i = torch.empty((nc * nq, k), dtype=torch.long, device=DEV)
+    from vision3d_amd import _lib
+
+    assert _lib.lib().v3d_knn_pack_uses_cell_list(nc, nc * nq, nc * ns, k) == 1
     ext.knn_pack(q, s, ql, sl, d, i, k)
     # brute force per cloud with torch (fp32 differences, same expression order)
     for c in range(nc):
@@ -389,8 +410,11 @@ def test_ops_knn_large_3d_clouds_take_the_cell_list_and_agree_with_the_batch_ker
     from vision3d_amd import ops
 
     g = torch.Generator().manual_seed(11)
-    q = torch.rand((2, 3000, 3), generator=g).to(DEV)
+    q = torch.rand((2, 20000, 3), generator=g).to(DEV)
     s = torch.rand((2, 9000, 3), generator=g).to(DEV)
+    from vision3d_amd import _lib
+
+    assert _lib.lib().v3d_knn_pack_uses_cell_list(2, 40000, 18000, 20) == 1
     s[1, 100:200] = s[1, :100]  # duplicates: equal distances
     for k in (1, 3, 20):
         d, i = ops.knn(q, s, k, return_distance=True)

@@ -1103,7 +1103,7 @@ def test_next_row_entry_points_take_caller_owned_workspaces():
              lambda: [orow2, ocol2, osc2, num])
     assert lib.v3d_threshold_select_workspace_bytes(100, 100) == 0  # one-launch size: no scratch at all
     # pack-mode radius search and kNN: pair-by-pair route (small clouds) and cell-list route (clouds of >= 2048 supports)
-    for lens_s, lens_q in (((300, 200), (100, 150)), ((3000, 2500), (400, 300))):
+    for lens_s, lens_q in (((300, 200), (100, 150)), ((3000, 2500), (70000, 60000))):
         ns, nq = sum(lens_s), sum(lens_q)
         sp = torch.rand((ns, 3), generator=g).to(DEV)
         qp = torch.rand((nq, 3), generator=g).to(DEV)
@@ -1111,6 +1111,7 @@ def test_next_row_entry_points_take_caller_owned_workspaces():
         ql = torch.tensor(lens_q, device=DEV)
         kd = torch.zeros((nq, 5), device=DEV)
         ki = torch.zeros((nq, 5), dtype=torch.long, device=DEV)
+        assert lib.v3d_knn_pack_uses_cell_list(2, nq, ns, 5) == (1 if ns > 4096 else 0)
         both(lib.v3d_knn_pack_workspace_bytes(2, ns, 5),
              lambda p, n: lib.v3d_knn_pack_f32(qp.data_ptr(), sp.data_ptr(), ql.data_ptr(), sl.data_ptr(), kd.data_ptr(),
                                                ki.data_ptr(), 2, nq, ns, 5, p, n, dev, stream),

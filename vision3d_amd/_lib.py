@@ -79,6 +79,7 @@ SIGNATURES = {
     "v3d_radius_search_grid_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_int] + _WS + _TAIL),
     "v3d_knn_pack_workspace_bytes": (_c_size, [_c_int, _c_i64, _c_int]),
+    "v3d_knn_pack_uses_cell_list": (_c_int, [_c_int, _c_i64, _c_i64, _c_int]),
     "v3d_knn_pack_f32": (
         _c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_int] + _WS + _TAIL),
     "v3d_radius_count_pack_f32": (

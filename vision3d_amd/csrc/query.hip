@@ -1733,9 +1733,20 @@ static int knn_points(const T* q, const T* s, T* od, int64_t* oi, int B, int M, 
 }
 
 constexpr int kKnnPackMaxClouds = 1 << 20;
-static bool knn_pack_uses_cell_list(int B, int64_t total_s, int k) {
+// The cell list of radius.hip can serve the call (k <= 64, <= 4096 clouds averaging >= 2048 supports, 32-bit cell
+// counters): what v3d_knn_pack_workspace_bytes sizes the workspace for.
+static bool knn_pack_may_use_cell_list(int B, int64_t total_s, int k) {
   return k <= kKnnCellListMaxK && B >= 1 && B <= kKnnCellListMaxClouds && total_s / B >= 2048 &&
-         4096ll * B + 4ll * total_s + 1 < (int64_t)INT32_MAX;  // (the cell counters of radius.hip are 32-bit)
+         4096ll * B + 4ll * total_s + 1 < (int64_t)INT32_MAX;
+}
+// ... and is worth it: pair by pair costs ~1/2400 ns per (query, support) pair of a cloud, the cell list ~50 us of
+// launches + ~0.1 ns per support (counting sort) + ~0.6 ns per query (profiles/r03_knn_pack_cell_list.txt) -- a handful
+// of queries against a large cloud stay pair by pair.  The host only knows the totals: the average cloud decides.
+static bool knn_pack_uses_cell_list(int B, int64_t total_q, int64_t total_s, int k) {
+  if (!knn_pack_may_use_cell_list(B, total_s, k)) return false;
+  const double pairwise_ns = (double)total_q * ((double)total_s / B) / 2400.0;
+  const double cell_list_ns = 50000.0 + 0.1 * (double)total_s + 0.6 * (double)total_q;
+  return cell_list_ns < pairwise_ns;
 }
 
 static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, const int64_t* s_lengths, float* od,
@@ -1761,7 +1772,7 @@ static int knn_pack(const float* q, const float* s, const int64_t* q_lengths, co
   // Clouds of a few thousand supports and more: the cell list of the radius search (radius.hip) instead of every
   // (query, support) pair -- 480,000 queries in 30,000-point clouds: 6.0 ms -> see profiles/r03_knn_pack_cell_list.txt.
   // The host only knows the totals: the average cloud decides.
-  if (knn_pack_uses_cell_list(B, total_s, k))
+  if (knn_pack_uses_cell_list(B, total_q, total_s, k))
     return knn_pack_cell_list(q, s, q_lengths, s_lengths, od, oi, B, total_q, total_s, k, workspace, workspace_bytes, device,
                               stream_);
   DeviceGuard guard(device);
@@ -1807,8 +1818,12 @@ extern "C" {
 
 size_t v3d_knn_pack_workspace_bytes(int B, int64_t total_s, int k) {
   if (B < 0 || total_s < 0) return 0;
-  if (v3d::knn_pack_uses_cell_list(B, total_s, k)) return v3d::knn_pack_cell_list_workspace_bytes(B, total_s);
+  if (v3d::knn_pack_may_use_cell_list(B, total_s, k)) return v3d::knn_pack_cell_list_workspace_bytes(B, total_s);
   return v3d::align_up(sizeof(v3d::KnnPackPlan) * ((size_t)B + 1), 256);
+}
+
+int v3d_knn_pack_uses_cell_list(int B, int64_t total_q, int64_t total_s, int k) {
+  return (B >= 0 && total_q >= 0 && total_s >= 0 && v3d::knn_pack_uses_cell_list(B, total_q, total_s, k)) ? 1 : 0;
 }
 
 int v3d_knn_pack_f32(const float* q_points, const float* s_points, const int64_t* q_lengths, const int64_t* s_lengths,
