@@ -62,6 +62,9 @@ def main():
     oracle.set_threads(oracle.max_threads())
     t_end = time.time() + budget
     n_cases, bad = 0, 0
+    routes = [0, 0]  # knn_pack calls searched pair by pair / on the cell list
+    from vision3d_amd import _lib
+    lib = _lib.lib()
     while time.time() < t_end:
         which = rng.integers(0, 4)
         tag = None
@@ -98,10 +101,23 @@ def main():
                 continue
             tag = f"knn_pack {'cell-list' if big else 'pairwise'} sl{sl.tolist()} ql{ql.tolist()} k{k}"
             wd, wi = oracle.knn_pack(q, s, ql, sl, k)
-            d = torch.full((len(q), k), -1.0, device=DEV)
-            i = torch.full((len(q), k), -1, dtype=torch.long, device=DEV)
-            ext.knn_pack(T(q), T(s), T(ql), T(sl), d, i, k)
-            ok = np.array_equal(N_(i), wi) and np.array_equal(N_(d), wd)
+            # the cell list is only taken with enough queries to pay for its build: repeat every cloud's queries
+            rep = -(-250000 // len(q)) if big else 1
+            q_rep = np.concatenate([np.tile(c, (rep, 1)) for c in qc])
+            route = lib.v3d_knn_pack_uses_cell_list(B, len(q_rep), len(s), k)
+            routes[route] += 1
+            d = torch.full((len(q_rep), k), -1.0, device=DEV)
+            i = torch.full((len(q_rep), k), -1, dtype=torch.long, device=DEV)
+            ext.knn_pack(T(q_rep), T(s), T(ql * rep), T(sl), d, i, k)
+            gd, gi = N_(d), N_(i)
+            ok, qo, ro = True, 0, 0
+            for n in ql:
+                n = int(n)
+                for r in range(rep):
+                    rows = slice(ro + r * n, ro + (r + 1) * n)
+                    ok = ok and np.array_equal(gi[rows], wi[qo:qo + n]) and np.array_equal(gd[rows], wd[qo:qo + n])
+                qo += n
+                ro += n * rep
         else:  # radius search: whole call and caller-held grid at a smaller radius
             B = int(rng.integers(1, 4))
             sl = np.array([int(rng.integers(0, 3000)) for _ in range(B)])
@@ -131,7 +147,8 @@ def main():
             print("MISMATCH", tag, flush=True)
         if n_cases % 25 == 0:
             print(f"{n_cases} cases, {bad} mismatches", flush=True)
-    print(f"done: {n_cases} cases, {bad} mismatches (seed {seed})", flush=True)
+    print(f"done: {n_cases} cases, {bad} mismatches (seed {seed}); knn_pack routes: {routes[0]} pair by pair, "
+          f"{routes[1]} on the cell list", flush=True)
     sys.exit(1 if bad else 0)
 
 
